@@ -1,0 +1,81 @@
+"""ORACLE (test infrastructure) — guided stochastic Heun sampler for blind BWE.
+
+Follows /root/reference/testing/blind_bwe_sampler.py: predict_blind_bwe
+:619-769, move_timestep :509-516, get_denoised_estimate :152-157,
+get_rec_grads :75-135 (norm: 2 path), fit_params :533-595, and the known-filter
+variant predict_bwe('fc_A') :351-364 + predict :406-498.
+Noise is injected (list of tensors in the reference's draw order: prior first,
+then one per step) so runs are reproducible against the golden records (G8).
+"""
+import torch
+
+from . import bwe_utils as U
+from . import edm as E
+
+
+class OracleBlindSampler:
+    def __init__(self, net, cqt, edm_params, *, fs, audio_len, T=35, order=2, xi=0.2, start_sigma=0.2,
+                 nfft=4096, fc_init=(280, 285, 290, 295, 300), A_init=(-15, -17, -20, -25, -30),
+                 mu=(1000.0, 10.0), tol=(5e-3, 5e-3), max_iter=100, fcmin=20.0, Amin=-50.0,
+                 weighting="sqrt", filter_out_cqt_DC_Nyq=True):
+        self.net, self.cqt, self.p = net, cqt, edm_params
+        self.fs, self.audio_len, self.T, self.order, self.xi = fs, audio_len, T, order, xi
+        self.start_sigma, self.nfft = start_sigma, nfft
+        self.fc_init, self.A_init = fc_init, A_init
+        self.fit_kw = dict(fs=fs, nfft=nfft, mu=mu, tol=tol, max_iter=max_iter, fcmin=fcmin, Amin=Amin,
+                           weighting=weighting)
+        self.hpf = filter_out_cqt_DC_Nyq
+        self.freqs = U.bin_freqs(nfft, fs)
+
+    def denoised(self, x, t):
+        xd = E.denoiser(self.p, self.net, x, t.reshape(1, 1).expand(x.shape[0], 1) if t.dim() == 0 else t)
+        if self.hpf:
+            xd = self.cqt.apply_hpf_DC(xd)
+        return xd
+
+    def rec_grads(self, x_den, y, x, t, params):
+        H = U.design_filter(params[0], params[1], self.freqs)
+        rec = U.apply_filter(x_den, H, self.nfft)
+        norm = torch.linalg.norm(y - rec, dim=1, ord=2)
+        g, = torch.autograd.grad(norm.sum(), x)
+        s = self.xi / (torch.linalg.norm(g) / self.audio_len ** 0.5 + 1e-6)
+        return s * g / t
+
+    def evaluate(self, x, t, y, params, blind=True):
+        """One score evaluation. Returns score, x_den (detached), new params."""
+        x = x.detach().requires_grad_(True)
+        x_den = self.denoised(x, t)
+        xd2 = x_den.detach().clone()
+        if blind:
+            params, _ = U.fit_params(xd2, y, params, **self.fit_kw)
+        rg = self.rec_grads(x_den, y, x, t, params)
+        score = (xd2 - x.detach()) / t ** 2 - rg
+        return score, xd2, params
+
+    def predict_blind_bwe(self, y, noises, blind=True, params=None, record=None):
+        p = self.p
+        if params is None:
+            params = torch.tensor([list(self.fc_init), list(self.A_init)], dtype=torch.float32)
+        if self.start_sigma is None:
+            t = E.schedule(p, self.T)
+            x = noises[0] * t[0]
+        else:
+            t = E.schedule(p, self.T, self.start_sigma)
+            x = y + noises[0] * t[0]
+        gam = E.gamma(p, t)
+        for i in range(self.T):
+            t_hat = t[i] + gam[i] * t[i]
+            x_hat = x + ((t_hat ** 2 - t[i] ** 2) ** 0.5) * noises[1 + i]
+            score, xden, params = self.evaluate(x_hat, t_hat, y, params, blind)
+            d = -t_hat * score
+            h = t[i + 1] - t_hat
+            if record is not None:
+                record.append(dict(x_hat=x_hat.clone(), t_hat=t_hat.clone(), x_den=xden.clone(), params=params.clone()))
+            if t[i + 1] != 0 and self.order == 2:
+                x_prime = x_hat + h * d
+                score2, _, params = self.evaluate(x_prime, t[i + 1], y, params, blind)
+                d2 = -t[i + 1] * score2
+                x = x_hat + h * (0.5 * d + 0.5 * d2)
+            else:
+                x = x_hat + h * d
+        return x.detach(), params.detach()

@@ -1,0 +1,306 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+The reference's third-party CQT (cqt_nsgt_pytorch, absent) is replaced by
+oracle.nsgt.CQT_nsgt, so the CQT itself is NOT pinned by these vectors; the
+UNet body, the samplers, EDM, STFT/filter utilities and the filter fit are.
+Outputs are data only (inputs are re-derived from the seeds stored beside them).
+"""
+import contextlib
+import importlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim  # noqa: E402
+from oracle.nsgt import CQT_nsgt  # noqa: E402
+
+ref_shim.install(CQT_nsgt)
+torch.set_num_threads(8)
+
+edm_mod = importlib.import_module("diff_params.edm")
+bu = importlib.import_module("utils.blind_bwe_utils")
+net_mod = importlib.import_module("networks.cqtdiff+")
+samp_mod = importlib.import_module("testing.blind_bwe_sampler")
+
+SMALL_NS = [8, 8, 8, 8, 16, 16, 16]
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def save(name, **kw):
+    np.savez_compressed(os.path.join(HERE, name), **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in kw.items()})
+    print("wrote", name, {k: np.asarray(v.detach() if torch.is_tensor(v) else v).shape for k, v in kw.items()})
+
+
+# ---------------------------------------------------------------- G1: EDM
+def g1():
+    out = {}
+    cfgs = {
+        "formal": dict(sigma_data=0.063, sigma_min=1e-4, sigma_max=1.0, ro=8, Schurn=10, Stmin=0, Stmax=50, Snoise=1.0),
+        "brass": dict(sigma_data=0.15, sigma_min=1e-4, sigma_max=2.0, ro=9, Schurn=5, Stmin=0, Stmax=50, Snoise=1.0),
+        "train": dict(sigma_data=0.063, sigma_min=1e-5, sigma_max=10.0, ro=13, Schurn=5, Stmin=0, Stmax=50, Snoise=1.0),
+    }
+    for name, c in cfgs.items():
+        args = ref_shim.load_args()
+        for k, v in c.items():
+            args.diff_params[k] = v
+        e = edm_mod.EDM(args)
+        for N in (3, 35):
+            t = e.create_schedule(N)
+            t0 = e.create_schedule_from_initial_t(0.2, N)
+            out[f"{name}_sched_{N}"] = t
+            out[f"{name}_sched0_{N}"] = t0
+            out[f"{name}_gamma_{N}"] = e.get_gamma(t)
+        s = torch.tensor([1e-4, 0.01, 0.2, 0.2777, 1.0, 2.0])
+        out[f"{name}_sig"] = s
+        out[f"{name}_cskip"] = e.cskip(s)
+        out[f"{name}_cout"] = e.cout(s)
+        out[f"{name}_cin"] = e.cin(s)
+        out[f"{name}_cnoise"] = e.cnoise(s)
+        for k, v in c.items():
+            out[f"{name}_cfg_{k}"] = v
+    save("edm.npz", **out)
+
+
+# ---------------------------------------------------------------- G2-G5: STFT / filter
+def g2_5():
+    out = {}
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(2, 20000, generator=g) * 0.1
+    out["stft_seed"] = 1234
+    for nfft in (1024, 4096):
+        X = bu.apply_stft(x, nfft)
+        out[f"stft_{nfft}"] = X
+        f = torch.fft.rfftfreq(nfft, d=1 / 44100)
+        H = bu.design_filter(torch.tensor([3000.0, 5000.0]), torch.tensor([-20.0, -40.0]), f)
+        out[f"filt_{nfft}"] = bu.apply_filter(x, H, nfft)
+        out[f"ident_{nfft}"] = bu.apply_filter(x, torch.ones_like(H), nfft)
+    # design_filter + grads
+    for fs in (44100, 22050):
+        f = torch.fft.rfftfreq(4096, d=1 / fs)
+        cases = {
+            "k1": ([1000.0], [-20.0]),
+            "k5": ([280.0, 285.0, 290.0, 295.0, 300.0], [-15.0, -17.0, -20.0, -25.0, -30.0]),
+            "k4_onbin": ([float(f[100]), float(f[200]) + 1e-3, 4000.0, 9000.0], [-5.0, -12.0, -30.0, -45.0]),
+            "k2_nyq": ([5000.0, fs / 2 - 30.0], [-10.0, -50.0]),
+        }
+        for cname, (fc, A) in cases.items():
+            p = torch.tensor([fc, A], requires_grad=True)
+            H = bu.design_filter(p[0], p[1], f)
+            wv = torch.linspace(0.5, 1.5, H.shape[0])
+            gr, = torch.autograd.grad((H * wv).sum(), p)
+            out[f"df_{fs}_{cname}_p"] = p.detach()
+            out[f"df_{fs}_{cname}_H"] = H.detach()
+            out[f"df_{fs}_{cname}_g"] = gr
+    # weighted losses
+    X = bu.apply_stft(x, 4096)
+    Y = bu.apply_stft(x.flip(0) * 0.7, 4096)
+    f = torch.fft.rfftfreq(4096, d=1 / 44100)
+    H = bu.design_filter(torch.tensor([1000.0, 3000.0]), torch.tensor([-10.0, -30.0]), f)
+    for wname in ("sqrt", "linear", "None", "log"):
+        out[f"loss_{wname}"] = bu.apply_filter_and_norm_STFTmag_fweighted(X, Y, H, wname)
+    save("stft_filter.npz", **out)
+
+    # G5 fit_params through the reference sampler class
+    out = {}
+    args = ref_shim.load_args(exp="maestro44k_8s")
+    with quiet():
+        s = samp_mod.BlindSampler(None, edm_mod.EDM(args), args)
+    s.freqs = torch.fft.rfftfreq(4096, d=1 / 44100)
+    for ci, (seed, B, fc_true, A_true, n) in enumerate([(11, 1, 3000.0, -30.0, 40000), (12, 2, 1000.0, -20.0, 30000),
+                                                         (13, 1, 6000.0, -45.0, 40000)]):
+        g = torch.Generator().manual_seed(seed)
+        xd = torch.randn(B, n, generator=g) * 0.1
+        Ht = bu.design_filter(torch.tensor([fc_true]), torch.tensor([A_true]), s.freqs)
+        y = bu.apply_filter(xd, Ht, 4096) + 1e-3 * torch.randn(B, n, generator=g)
+        p0 = torch.tensor([[280.0, 285.0, 290.0, 295.0, 300.0], [-15.0, -17.0, -20.0, -25.0, -30.0]])
+        # record trajectory by running the reference with max_iter = 1..k is too slow; run once for the final
+        with quiet(), contextlib.redirect_stderr(io.StringIO()):
+            pf = s.fit_params(xd.clone(), y.clone(), p0.clone())
+        out[f"fit{ci}_seed"] = seed
+        out[f"fit{ci}_B"] = B
+        out[f"fit{ci}_n"] = n
+        out[f"fit{ci}_true"] = np.array([fc_true, A_true])
+        out[f"fit{ci}_final"] = pf.detach()
+        for mi in (1, 2, 5):
+            args.tester.blind_bwe.optimization.max_iter = mi
+            with quiet(), contextlib.redirect_stderr(io.StringIO()):
+                out[f"fit{ci}_it{mi}"] = s.fit_params(xd.clone(), y.clone(), p0.clone()).detach()
+        args.tester.blind_bwe.optimization.max_iter = 100
+    save("fit_params.npz", **out)
+
+
+# ---------------------------------------------------------------- G6: blocks
+def scale_gates(sd, seed=5):
+    """init_zero gates (1e-7) make residual branches numerically invisible: rescale to O(1)."""
+    g = torch.Generator().manual_seed(seed)
+    for k in sd:
+        if ".gate." in k:
+            sd[k] = torch.randn(sd[k].shape, generator=g) * (0.1 if k.endswith("weight") else 0.5)
+        if ".norm." in k and k.endswith("gamma"):
+            sd[k] = 1.0 + 0.2 * torch.randn(sd[k].shape, generator=g)
+        if ".affine." in k and k.endswith("bias"):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+    return sd
+
+
+def g6():
+    out = {}
+    init = dict(init_mode="kaiming_uniform", init_weight=np.sqrt(1 / 3))
+    init_zero = dict(init_mode="kaiming_uniform", init_weight=1e-7)
+    g = torch.Generator().manual_seed(77)
+    emb = torch.relu(torch.randn(2, 32, generator=g))
+    out["emb"] = emb
+    specs = {
+        "b53": dict(dim=8, dim_out=16, num_dils=3, kernel_size=(5, 3), proj_place="before"),
+        "b11": dict(dim=2, dim_out=8, num_dils=1, kernel_size=(1, 1), proj_place="before"),
+        "bout": dict(dim=16, dim_out=2, num_dils=1, kernel_size=(1, 1), proj_place="after"),
+        "bsame": dict(dim=16, dim_out=16, num_dils=2, kernel_size=(5, 3), proj_place="before"),
+    }
+    for name, sp in specs.items():
+        torch.manual_seed(100 + len(name))
+        blk = net_mod.ResnetBlock(sp["dim"], sp["dim_out"], True, num_dils=sp["num_dils"], bias=False,
+                                  kernel_size=sp["kernel_size"], emb_dim=32, proj_place=sp["proj_place"],
+                                  init=init, init_zero=init_zero)
+        sd = scale_gates({k: v.clone() for k, v in blk.state_dict().items()})
+        blk.load_state_dict(sd)
+        x = torch.randn(2, sp["dim"], 64, 24, generator=g, requires_grad=True)
+        y = blk(x, emb)
+        wv = torch.randn(y.shape, generator=g)
+        gx, = torch.autograd.grad((y * wv).sum(), x)
+        for k, v in sd.items():
+            out[f"{name}.sd.{k}"] = v
+        out[f"{name}.x"] = x.detach()
+        out[f"{name}.y"] = y.detach()
+        out[f"{name}.wv"] = wv
+        out[f"{name}.gx"] = gx
+    gn = net_mod.BiasFreeGroupNorm(16, 8)
+    x = torch.randn(2, 16, 5, 7, generator=g) + 0.3
+    out["gn.x"] = x
+    out["gn.y"] = gn(x).detach()
+    dn = net_mod.UpDownResample(down=True, mode_resample="T")
+    up = net_mod.UpDownResample(up=True, mode_resample="T")
+    for T in (16, 22):
+        x = torch.randn(2, 3, 4, T, generator=g)
+        out[f"rs.x{T}"] = x
+        out[f"rs.down{T}"] = dn(x)
+        out[f"rs.up{T}"] = up(x)
+    torch.manual_seed(3)
+    rff = net_mod.RFF_MLP_Block(emb_dim=32, init=init)
+    s = torch.tensor([[-2.3], [0.1]])
+    for k, v in rff.state_dict().items():
+        out[f"rff.sd.{k}"] = v
+    out["rff.s"] = s
+    out["rff.y"] = rff(s).detach()
+    save("blocks.npz", **out)
+
+
+# ---------------------------------------------------------------- G7/G8: UNet + sampler
+def small_args(T=3, L=92092, fs=22050):
+    args = ref_shim.load_args(exp="maestro22k_8s")
+    args.exp.audio_len = L
+    args.exp.sample_rate = fs
+    args.network.Ns = list(SMALL_NS)
+    args.tester.T = T
+    return args
+
+
+def build_ref_net(args, seed=0, out_scale=1.0):
+    torch.manual_seed(seed)
+    with quiet():
+        net = net_mod.Unet_CQT_oct_with_attention(args, "cpu")
+    sd = scale_gates({k: v.clone() for k, v in net.state_dict().items()})
+    # out_scale < 1 shrinks the (random, untrained) network's contribution to the denoised
+    # estimate so that the per-step filter fit is a well-conditioned problem (a random net
+    # produces estimates for which the reference's own 100-iteration fit is chaotic).
+    for k in sd:
+        if (k.startswith("middle.0.0.") or (k.startswith("ups.") and k.split(".")[2] == "0")) and \
+                (k.endswith("proj_out.weight") or k.endswith("res_conv.weight")):
+            sd[k] = sd[k] * out_scale
+    net.load_state_dict(sd)
+    return net, sd
+
+
+def g7_8():
+    args = small_args(T=3)
+    net, sd = build_ref_net(args)
+    out = {f"sd.{k}": v for k, v in sd.items()}
+    L = args.exp.audio_len
+    g = torch.Generator().manual_seed(2024)
+    x = (0.1 * torch.randn(1, L, generator=g)).requires_grad_(True)
+    cn = torch.tensor([[-0.4]])
+    y = net(x, cn)
+    wv = torch.randn(y.shape, generator=g)
+    gx, = torch.autograd.grad((y * wv).sum(), x)
+    out["unet_seed"] = 2024
+    out["unet_cnoise"] = cn
+    out["unet_y"] = y.detach()
+    out["unet_gx"] = gx
+    save("unet_small.npz", **out)
+
+    # sampler, T=3, recorded noise (by seed)
+    out = {}
+    # An untrained network gives denoised estimates for which the reference's own filter fit
+    # is chaotic (checked: 1-ulp input changes move fc by tens of Hz after 100 iterations), so
+    # the sampler goldens wrap it as  net'(x, c) = a*net(x, c) + (sigma/sigma_data)*x  with
+    # sigma = exp(4c):  D(x) = x + a*c_out*net(c_in x), a noisy-identity "denoiser" that keeps
+    # the fit well-posed while every byte of the UNet fwd/VJP still feeds the result.
+    class ResidualNet:
+        def __init__(self, inner, a, sigma_data):
+            self.inner, self.a, self.sd = inner, a, sigma_data
+            self.CQTransform = inner.CQTransform
+
+        def __call__(self, x, cnoise):
+            return self.a * self.inner(x, cnoise) + (torch.exp(4 * cnoise) / self.sd) * x
+
+    out["res_a"] = 0.3
+    args.tester.posterior_sampling.start_sigma = 0.05
+    out["start_sigma"] = 0.05
+    e = edm_mod.EDM(args)
+    with quiet():
+        s = samp_mod.BlindSampler(ResidualNet(net, 0.3, args.tester.diff_params.sigma_data), e, args)
+    g = torch.Generator().manual_seed(4242)
+    t_ax = torch.arange(L) / args.exp.sample_rate
+    clean = sum(0.05 / (k + 1) * torch.sin(2 * np.pi * 220.0 * (k + 1) * t_ax) * torch.exp(-t_ax * (1 + k)) for k in range(12))
+    clean = clean[None] + 0.1 * torch.randn(1, L, generator=g)
+    f = torch.fft.rfftfreq(4096, d=1 / args.exp.sample_rate)
+    Ht = bu.design_filter(torch.tensor([2000.0]), torch.tensor([-40.0]), f)
+    y = bu.apply_filter(clean, Ht, 4096)
+    noises = [torch.randn(1, L, generator=g) for _ in range(1 + args.tester.T)]
+    it = iter(noises)
+    orig_randn = torch.randn
+    torch.randn = lambda *a, **k: next(it)
+    try:
+        with quiet(), contextlib.redirect_stderr(io.StringIO()):
+            res = s.predict_blind_bwe(y.clone(), rid=True)
+    finally:
+        torch.randn = orig_randn
+    xres, fp, data_den, t, data_filt = res
+    out.update(seed=4242, y=y, x=xres, filter_params=fp, data_denoised=data_den, t=t, data_filters=data_filt)
+    # known-filter variant (predict_bwe 'fc_A') with the same noises
+    it = iter(noises)
+    torch.randn = lambda *a, **k: next(it)
+    try:
+        with quiet(), contextlib.redirect_stderr(io.StringIO()):
+            xk = s.predict_bwe(y.clone(), torch.tensor([[2000.0], [-40.0]]), "fc_A")
+    finally:
+        torch.randn = orig_randn
+    out["x_known"] = xk
+    save("sampler_small.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8"]
+    for w in which:
+        globals()[w]()
