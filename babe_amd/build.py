@@ -1,0 +1,60 @@
+"""Build libbabe_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libbabe_hip.so")
+SOURCES = ["misc.hip", "conv.hip", "norm.hip", "resample.hip", "fft.hip", "cqt.hip", "stft.hip", "sampler.hip"]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "babe_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for src in SOURCES:
+        p = os.path.join(CSRC, src)
+        if not os.path.exists(p):
+            continue
+        o = os.path.join(HERE, "build", src + ".o")
+        objs.append(o)
+        if (not force) and os.path.exists(o) and os.path.getmtime(o) > max(
+                os.path.getmtime(p), os.path.getmtime(os.path.join(CSRC, "common.h")),
+                os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "babe_hip.h"))):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", p, "-o", o,
+               "-Wno-unused-result"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            failed = True
+            print(f"--- {src} FAILED\n{out}", file=sys.stderr)
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

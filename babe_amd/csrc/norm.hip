@@ -1,0 +1,252 @@
+// BiasFreeGroupNorm (no mean removal) + FiLM + exact GELU, forward and input-VJP.
+// Reference: /root/reference/networks/cqtdiff+.py:147-163 (torch.std, unbiased) and :472-482.
+//   fwd:  a = gelu( x / (std_g + eps) * gamma_c * (film_c + 1) )  =  gelu(x * scale[b][c])
+//   vjp:  du = da * gelu'(x*scale);  gx = scale*du - (x-mean_g) * S_g / ((n-1) std (std+eps)^2),
+//         S_g = sum_g( du * scale*(std+eps) * x )            
+// All of these are HBM-bound streaming kernels: float4 loads, wave-shuffle + LDS tree reductions,
+// double accumulation for the statistics.
+#include "common.h"
+#include "../../include/babe_hip.h"
+
+namespace {
+
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
+
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.f + erff(u * kInvSqrt2)); }
+__device__ __forceinline__ float gelu_grad_f(float u) {
+    return 0.5f * (1.f + erff(u * kInvSqrt2)) + u * kInvSqrt2Pi * __expf(-0.5f * u * u);
+}
+
+__device__ __forceinline__ void block_reduce2(double& s0, double& s1, double* sh) {
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[wave * 2] = s0;
+        sh[wave * 2 + 1] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+            a += sh[w * 2];
+            b += sh[w * 2 + 1];
+        }
+        s0 = a;
+        s1 = b;
+    }
+}
+
+// grid: (S, B*G)
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                         long n, int S) {
+    __shared__ double sh[8];
+    const int s = blockIdx.x;
+    const long bg = blockIdx.y;
+    const long chunk = ((n / 4 + S - 1) / S) * 4;       // multiple of 4 elements
+    const long beg = (long)s * chunk;
+    long end = beg + chunk;
+    if (end > n) end = n;
+    const float* p = x + bg * n;
+    double s0 = 0, s1 = 0;
+    if (beg < end) {
+        const long nv = (end - beg) / 4;
+        const float4* p4 = reinterpret_cast<const float4*>(p + beg);
+        for (long i = threadIdx.x; i < nv; i += blockDim.x) {
+            const float4 v = p4[i];
+            s0 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            s1 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+        for (long i = beg + nv * 4 + threadIdx.x; i < end; i += blockDim.x) {
+            const double v = p[i];
+            s0 += v;
+            s1 += v * v;
+        }
+    }
+    block_reduce2(s0, s1, sh);
+    if (threadIdx.x == 0) {
+        part[(bg * S + s) * 2] = s0;
+        part[(bg * S + s) * 2 + 1] = s1;
+    }
+}
+
+// one block per (b); threads over channels
+__global__ void gn_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+                                   const float* __restrict__ film, long film_bs, float* __restrict__ stats,
+                                   float* __restrict__ scale, int C, int G, long n, int S, float eps) {
+    const int b = blockIdx.x;
+    __shared__ float rstd_sh[64];
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        double s0 = 0, s1 = 0;
+        for (int s = 0; s < S; ++s) {
+            s0 += part[((long)(b * G + g) * S + s) * 2];
+            s1 += part[((long)(b * G + g) * S + s) * 2 + 1];
+        }
+        const double mean = s0 / (double)n;
+        double var = (s1 - (double)n * mean * mean) / (double)(n - 1);
+        if (var < 0) var = 0;
+        const float sd = (float)sqrt(var);
+        const float r = 1.f / (sd + eps);
+        stats[(b * G + g) * 3 + 0] = (float)mean;
+        stats[(b * G + g) * 3 + 1] = sd;
+        stats[(b * G + g) * 3 + 2] = r;
+        rstd_sh[g] = r;
+    }
+    __syncthreads();
+    const int cg = C / G;
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+        scale[b * C + c] = gamma[c] * (film[(long)b * film_bs + c] + 1.f) * rstd_sh[c / cg];
+}
+
+// grid: (blocks over hw/4, C, B)
+__global__ __launch_bounds__(256) void scale_gelu_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         float* __restrict__ a, int C, long hw) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float sc = scale[b * C + c];
+    const long base = ((long)b * C + c) * hw;
+    const long nv = hw / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    float4* a4 = reinterpret_cast<float4*>(a + base);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        float4 v = x4[i];
+        v.x = gelu_f(v.x * sc);
+        v.y = gelu_f(v.y * sc);
+        v.z = gelu_f(v.z * sc);
+        v.w = gelu_f(v.w * sc);
+        a4[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (long i = nv * 4 + threadIdx.x; i < hw; i += blockDim.x) a[base + i] = gelu_f(x[base + i] * sc);
+}
+
+// grid: (S, B*G).  A group is cg channels of hw elements, contiguous: n = cg*hw.
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, float* __restrict__ dadu,
+                                                             const float* __restrict__ scale,
+                                                             double* __restrict__ part, int C, int G, long hw, int S) {
+    __shared__ double sh[8];
+    const int s = blockIdx.x;
+    const int bg = blockIdx.y;
+    const int b = bg / G, g = bg % G;
+    const int cg = C / G;
+    const long n = (long)cg * hw;
+    const long chunk = ((n / 4 + S - 1) / S) * 4;
+    const long beg = (long)s * chunk;
+    long end = beg + chunk;
+    if (end > n) end = n;
+    const long base = ((long)b * C + (long)g * cg) * hw;
+    double s0 = 0, s1 = 0;
+    // hw is a multiple of 4 (checked on the host) so a float4 never straddles two channels
+    for (long i = beg + (long)threadIdx.x * 4; i < end; i += (long)blockDim.x * 4) {
+        const int c = g * cg + (int)(i / hw);
+        const float sc = scale[b * C + c];
+        const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+        float4 dv = *reinterpret_cast<const float4*>(dadu + base + i);
+        dv.x *= gelu_grad_f(xv.x * sc);
+        dv.y *= gelu_grad_f(xv.y * sc);
+        dv.z *= gelu_grad_f(xv.z * sc);
+        dv.w *= gelu_grad_f(xv.w * sc);
+        *reinterpret_cast<float4*>(dadu + base + i) = dv;
+        s0 += (double)sc * ((double)dv.x * xv.x + (double)dv.y * xv.y + (double)dv.z * xv.z + (double)dv.w * xv.w);
+    }
+    block_reduce2(s0, s1, sh);
+    if (threadIdx.x == 0) part[(long)bg * S + s] = s0;
+}
+
+// grid: (blocks, C, B)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ du,
+                                                           const float* __restrict__ gy,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ stats,
+                                                           const double* __restrict__ part, float* __restrict__ gx,
+                                                           float rbeta, int C, int G, long hw, int S, float eps) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int cg = C / G;
+    const int g = c / cg;
+    const long n = (long)cg * hw;
+    double S1 = 0;
+    for (int s = 0; s < S; ++s) S1 += part[(long)(b * G + g) * S + s];
+    const float mean = stats[(b * G + g) * 3 + 0];
+    const float sd = stats[(b * G + g) * 3 + 1];
+    // S1 was accumulated with scale = k/(sd+eps); the formula needs sum(k*du*x) = S1*(sd+eps)
+    const double se = (double)sd + eps;
+    const float coef = (sd > 0.f) ? (float)(S1 * se / ((double)(n - 1) * sd * se * se)) : 0.f;
+    const float sc = scale[b * C + c];
+    const long base = ((long)b * C + c) * hw;
+    const long nv = hw / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    const float4* d4 = reinterpret_cast<const float4*>(du + base);
+    const float4* g4 = gy ? reinterpret_cast<const float4*>(gy + base) : nullptr;
+    float4* o4 = reinterpret_cast<float4*>(gx + base);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        const float4 xv = x4[i], dv = d4[i];
+        float4 o;
+        o.x = sc * dv.x - (xv.x - mean) * coef;
+        o.y = sc * dv.y - (xv.y - mean) * coef;
+        o.z = sc * dv.z - (xv.z - mean) * coef;
+        o.w = sc * dv.w - (xv.w - mean) * coef;
+        if (g4) {
+            const float4 gv = g4[i];
+            o.x += rbeta * gv.x;
+            o.y += rbeta * gv.y;
+            o.z += rbeta * gv.z;
+            o.w += rbeta * gv.w;
+        }
+        o4[i] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int babe_gn_partial(const float* x, double* part, int B, int G, long n, int S, void* stream) {
+    BABE_CHECK_ARG(x && part && B > 0 && G > 0 && n > 1 && S > 0, "gn_partial: bad arguments");
+    BABE_CHECK_ARG(n % 4 == 0, "gn_partial: group size %ld not a multiple of 4", n);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(S, B * G), dim3(256), 0, (hipStream_t)stream, x, part, n, S);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_gn_finalize(const double* part, const float* gamma, const float* film, long film_bs, float* stats,
+                                float* scale, int B, int C, int G, long n, int S, float eps, void* stream) {
+    BABE_CHECK_ARG(part && gamma && film && stats && scale, "gn_finalize: null pointer");
+    BABE_CHECK_ARG(G <= 64 && C % G == 0, "gn_finalize: C=%d G=%d unsupported", C, G);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, part, gamma, film, film_bs,
+                       stats, scale, C, G, n, S, eps);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_scale_gelu(const float* x, const float* scale, float* a, int B, int C, long hw, void* stream) {
+    BABE_CHECK_ARG(x && scale && a && B > 0 && C > 0 && hw > 0, "scale_gelu: bad arguments");
+    BABE_CHECK_ARG(hw % 4 == 0, "scale_gelu: plane size %ld not a multiple of 4", hw);
+    int bx = cdiv(hw / 4, 256 * 4);
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(scale_gelu_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, scale, a, C, hw);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_gn_bwd_partial(const float* x, float* da_du, const float* scale, double* part, int B, int C,
+                                   int G, long hw, int S, void* stream) {
+    BABE_CHECK_ARG(x && da_du && scale && part, "gn_bwd_partial: null pointer");
+    BABE_CHECK_ARG(hw % 4 == 0 && C % G == 0, "gn_bwd_partial: hw=%ld C=%d G=%d unsupported", hw, C, G);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(S, B * G), dim3(256), 0, (hipStream_t)stream, x, da_du, scale,
+                       part, C, G, hw, S);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_gn_bwd_apply(const float* x, const float* du, const float* gy, const float* scale,
+                                 const float* stats, const double* part, float* gx, float rbeta, int B, int C, int G,
+                                 long hw, int S, float eps, void* stream) {
+    BABE_CHECK_ARG(x && du && scale && stats && part && gx, "gn_bwd_apply: null pointer");
+    BABE_CHECK_ARG(hw % 4 == 0 && C % G == 0, "gn_bwd_apply: hw=%ld C=%d G=%d unsupported", hw, C, G);
+    int bx = cdiv(hw / 4, 256 * 4);
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, du, gy, scale, stats,
+                       part, gx, rbeta, C, G, hw, S, eps);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}

@@ -1,0 +1,150 @@
+"""Python views of the babe_hip C-ABI ops (UNet building blocks).  Device tensors only."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvArgs, check, lib, ptr, stream
+
+RSQRT2 = 1.0 / math.sqrt(2.0)
+
+
+def _view(t):
+    """(ptr, batch stride, channel stride) of a [B,C,F,T] tensor whose rows are contiguous."""
+    assert t.dim() == 4 and t.dtype == torch.float32
+    assert t.stride(3) == 1 and t.stride(2) == t.shape[3], f"rows must be contiguous, got strides {t.stride()}"
+    return ptr(t), t.stride(0), t.stride(1)
+
+
+class PackedConv:
+    """Conv2d weights packed for babe_conv2d, forward and input-VJP (flipped/transposed) versions."""
+
+    def __init__(self, w):
+        assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 4
+        w = w.contiguous()
+        self.Cout, self.Cin, self.KH, self.KW = w.shape
+        L = lib()
+        nf = L.babe_conv_packed_size(self.Cout, self.Cin, self.KH, self.KW, 0)
+        nb = L.babe_conv_packed_size(self.Cout, self.Cin, self.KH, self.KW, 1)
+        self.fwd = torch.empty(nf, device=w.device, dtype=torch.float32)
+        self.bwd = torch.empty(nb, device=w.device, dtype=torch.float32)
+        check(L.babe_conv_pack_weights(ptr(w), ptr(self.fwd), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack")
+        check(L.babe_conv_pack_weights(ptr(w), ptr(self.bwd), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack")
+
+
+def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=None, oscale=None, alpha=1.0, rbeta=0.0):
+    """out = alpha*conv(x[,x2]; W)*oscale + rbeta*res   (transpose=True: input-VJP weights)."""
+    a = ConvArgs()
+    B, C1, F, T = x.shape
+    Cin = pc.Cout if transpose else pc.Cin
+    Cout = pc.Cin if transpose else pc.Cout
+    a.in_, a.in_bs, a.in_cs = _view(x)
+    if x2 is not None:
+        assert x2.shape[0] == B and x2.shape[2:] == x.shape[2:]
+        a.in2, a.in2_bs, a.in2_cs = _view(x2)
+        a.cin_split = C1
+        assert C1 + x2.shape[1] == Cin
+    else:
+        a.in2, a.in2_bs, a.in2_cs, a.cin_split = None, 0, 0, Cin
+        assert C1 == Cin, (C1, Cin)
+    a.w_packed = ptr(pc.bwd if transpose else pc.fwd)
+    assert out.shape == (B, Cout, F, T), (out.shape, (B, Cout, F, T))
+    a.out, a.out_bs, a.out_cs = _view(out)
+    if res is not None:
+        assert res.shape == out.shape
+        a.res, a.res_bs, a.res_cs = _view(res)
+    else:
+        a.res, a.res_bs, a.res_cs = None, 0, 0
+    if in_scale is not None:
+        assert in_scale.is_contiguous() and in_scale.shape == (B, Cin)
+    if oscale is not None:
+        assert oscale.is_contiguous() and oscale.shape == (B, Cout)
+    a.in_scale, a.oscale = ptr(in_scale), ptr(oscale)
+    a.alpha, a.rbeta = alpha, rbeta
+    a.B, a.Cin, a.Cout, a.F, a.T = B, Cin, Cout, F, T
+    a.KH, a.KW, a.dil = pc.KH, pc.KW, dil
+    check(lib().babe_conv2d(C.byref(a), stream()), "conv2d")
+    return out
+
+
+def _splits(n, B, G):
+    s = max(1, min(64, n // 16384))
+    return int(s)
+
+
+def gn_scale(x, gamma, film, G=8, eps=1e-7):
+    """Returns (stats [B,G,3], scale [B,C]) with scale = gamma*(film+1)/(std+eps).  x dense [B,C,F,T]."""
+    assert x.is_contiguous()
+    B, Cc, F, T = x.shape
+    n = (Cc // G) * F * T
+    S = _splits(n, B, G)
+    part = torch.empty(B * G * S * 2, device=x.device, dtype=torch.float64)
+    stats = torch.empty(B, G, 3, device=x.device, dtype=torch.float32)
+    scale = torch.empty(B, Cc, device=x.device, dtype=torch.float32)
+    L = lib()
+    check(L.babe_gn_partial(ptr(x), ptr(part), B, G, n, S, stream()), "gn_partial")
+    assert film.stride(1) == 1
+    check(L.babe_gn_finalize(ptr(part), ptr(gamma), ptr(film), film.stride(0), ptr(stats), ptr(scale), B, Cc, G, n, S,
+                             eps, stream()), "gn_finalize")
+    return stats, scale
+
+
+def scale_gelu(x, scale, out):
+    B, Cc, F, T = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape
+    check(lib().babe_scale_gelu(ptr(x), ptr(scale), ptr(out), B, Cc, F * T, stream()), "scale_gelu")
+    return out
+
+
+def gn_bwd(x, da, gy, scale, stats, gx, rbeta, G=8, eps=1e-7):
+    """da is overwritten with du; gx = rbeta*gy + GN/FiLM/GELU input-VJP (gx may alias gy)."""
+    B, Cc, F, T = x.shape
+    assert x.is_contiguous() and da.is_contiguous() and gx.is_contiguous() and (gy is None or gy.is_contiguous())
+    n = (Cc // G) * F * T
+    S = _splits(n, B, G)
+    part = torch.empty(B * G * S, device=x.device, dtype=torch.float64)
+    L = lib()
+    check(L.babe_gn_bwd_partial(ptr(x), ptr(da), ptr(scale), ptr(part), B, Cc, G, F * T, S, stream()), "gn_bwd_partial")
+    check(L.babe_gn_bwd_apply(ptr(x), ptr(da), ptr(gy), ptr(scale), ptr(stats), ptr(part), ptr(gx), rbeta, B, Cc, G,
+                              F * T, S, eps, stream()), "gn_bwd_apply")
+    return gx
+
+
+def resample(x, out, mode, alpha=1.0, beta=0.0):
+    """mode 0 down, 1 up, 2 down^T, 3 up^T. T argument is the forward op's input length."""
+    B, Cc, F, Tin = x.shape
+    T = {0: Tin, 1: Tin, 2: Tin * 2, 3: Tin // 2}[mode]
+    Tout = {0: T // 2, 1: 2 * T, 2: T, 3: T}[mode]
+    assert out.shape == (B, Cc, F, Tout), (out.shape, (B, Cc, F, Tout))
+    xp, xbs, xcs = _view(x)
+    op, obs, ocs = _view(out)
+    check(lib().babe_resample(xp, xbs, xcs, op, obs, ocs, B, Cc, F, T, mode, alpha, beta, stream()), "resample")
+    return out
+
+
+def axpby(x, out, alpha=1.0, beta=0.0):
+    assert x.shape == out.shape
+    B, Cc, F, T = x.shape
+    xp, xbs, xcs = _view(x)
+    op, obs, ocs = _view(out)
+    check(lib().babe_axpby4d(xp, xbs, xcs, op, obs, ocs, B, Cc, F, T, alpha, beta, stream()), "axpby4d")
+    return out
+
+
+def linear(x, W, bias, relu=False, out=None):
+    B, K = x.shape
+    J = W.shape[0]
+    assert x.is_contiguous() and W.is_contiguous()
+    if out is None:
+        out = torch.empty(B, J, device=x.device, dtype=torch.float32)
+    check(lib().babe_linear(ptr(x), ptr(W), ptr(bias), ptr(out), B, K, J, int(relu), stream()), "linear")
+    return out
+
+
+def rff(cnoise, freq):
+    B = cnoise.shape[0]
+    R = freq.numel()
+    out = torch.empty(B, 2 * R, device=cnoise.device, dtype=torch.float32)
+    check(lib().babe_rff(ptr(cnoise.contiguous()), ptr(freq.contiguous()), ptr(out), B, R, stream()), "rff")
+    return out

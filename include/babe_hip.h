@@ -1,0 +1,82 @@
+/* babe_hip.h — C-ABI of the MI355X (gfx950) kernels behind the BABE blind-BWE hot path.
+ *
+ * The reference (eloimoliner/BABE) has no FFI: its "plug-in" boundary is Python classes
+ * (utils/setup.py:47-96).  Each entry point below replaces the ATen call(s) cited beside it.
+ * Conventions: raw device pointers (fp32 unless noted), explicit shapes/strides (in ELEMENTS),
+ * hipStream_t passed as void*, every call is asynchronous on that stream, returns 0 on success
+ * or a negative code (message: babe_last_error()).  The library never allocates on the hot
+ * path; the caller owns all buffers and workspaces.
+ */
+#ifndef BABE_HIP_H
+#define BABE_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* babe_version(void);
+const char* babe_last_error(void);
+
+/* Strided 4-D tensor view [B][C][F][T], T contiguous, row stride = T. */
+typedef struct { float* p; long bs; long cs; } babe_view;
+
+/* ---- Conv2d "same", no bias: networks/cqtdiff+.py:79-88 (F.conv2d) ------------------------
+ * w_packed: [KH][KW][CinP][CoutP] from babe_conv_pack_weights (CinP = ceil8(Cin), CoutP = ceil32(Cout)).
+ * Input channels [0,cin_split) come from `in`, [cin_split,Cin) from `in2` (torch.cat dim=1, :814).
+ * out = alpha * acc * oscale[b,co] * (in_scale folded per input channel) + rbeta * res      */
+typedef struct {
+    const float* in;  long in_bs,  in_cs;
+    const float* in2; long in2_bs, in2_cs; int cin_split;
+    const float* w_packed;
+    float* out;       long out_bs, out_cs;
+    const float* res; long res_bs, res_cs;
+    const float* in_scale;   /* [B][Cin] or NULL  */
+    const float* oscale;     /* [B][Cout] or NULL */
+    float alpha, rbeta;
+    int B, Cin, Cout, F, T, KH, KW, dil;
+} babe_conv_args;
+int babe_conv2d(const babe_conv_args* a, void* stream);
+/* w: [Cout][Cin][KH][KW] (reference layout) -> packed; transpose_flip=1 builds the bwd-data weights
+ * (w'[ci][co][KH-1-kh][KW-1-kw]) so that babe_conv2d computes the input-VJP (replaces autograd's
+ * convolution_backward for the input).  dst size = KH*KW*ceil8(Cin')*ceil32(Cout') floats. */
+int babe_conv_pack_weights(const float* w, float* dst, int Cout, int Cin, int KH, int KW,
+                           int transpose_flip, void* stream);
+long babe_conv_packed_size(int Cout, int Cin, int KH, int KW, int transpose_flip);
+
+/* ---- BiasFreeGroupNorm + FiLM + GELU: cqtdiff+.py:147-163, :472-482 ------------------------ */
+/* partial sums (double) of x and x^2 per (b,group,split): part[(b*G+g)*S+s] = {sum, sumsq} */
+int babe_gn_partial(const float* x, double* part, int B, int G, long n_per_group, int S, void* stream);
+/* stats[b*G+g] = {mean, std, 1/(std+eps)}; scale[b][c] = gamma[c]*(film[b][c]+1)/(std+eps) */
+int babe_gn_finalize(const double* part, const float* gamma, const float* film, long film_bs,
+                     float* stats, float* scale, int B, int C, int G, long n_per_group, int S,
+                     float eps, void* stream);
+/* a = gelu(x * scale[b][c]) */
+int babe_scale_gelu(const float* x, const float* scale, float* a, int B, int C, long hw, void* stream);
+/* VJP pass 1: du = da * gelu'(x*scale) written in place over da; part[(b*G+g)*S+s] = sum(du * scale*(std+eps) * x) */
+int babe_gn_bwd_partial(const float* x, float* da_du, const float* scale, double* part,
+                        int B, int C, int G, long hw, int S, void* stream);
+/* VJP pass 2: gx = rbeta*gy + scale*du - (x-mean)*coef_g ; coef from part and stats */
+int babe_gn_bwd_apply(const float* x, const float* du, const float* gy, const float* scale,
+                      const float* stats, const double* part, float* gx, float rbeta,
+                      int B, int C, int G, long hw, int S, float eps, void* stream);
+
+/* ---- UpDownResample ('cubic', reflect): cqtdiff+.py:549-580 (conv1d / conv_transpose1d with a
+ * dense diagonal weight) as a depth-wise 8-tap polyphase FIR.  mode: 0 down, 1 up, 2 down^T, 3 up^T.
+ * T = time length of the INPUT of the forward op (for the adjoints: of the forward op's input too). */
+int babe_resample(const float* in, long in_bs, long in_cs, float* out, long out_bs, long out_cs,
+                  int B, int C, int F, int T, int mode, float alpha, float beta, void* stream);
+
+/* ---- strided copy / axpby: out = alpha*in + beta*out on [B][C][F][T] views (torch.cat / slicing /
+ * (a+b)/sqrt2 residual merges, cqtdiff+.py:769-774,794,814-822) */
+int babe_axpby4d(const float* in, long in_bs, long in_cs, float* out, long out_bs, long out_cs,
+                 int B, int C, int F, int T, float alpha, float beta, void* stream);
+
+/* ---- small dense: out[b][j] = act(sum_k x[b][k] W[j][k] + bias[j]); Linear :36-40, RFF_MLP :184-211 */
+int babe_linear(const float* x, const float* W, const float* bias, float* out, int B, int K, int J,
+                int relu, void* stream);
+/* table = 2*pi*cnoise[b]*freq[j]; out[b] = [sin(table), cos(table)]  (:199-211) */
+int babe_rff(const float* cnoise, const float* freq, float* out, int B, int R, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,139 @@
+"""HIP ops (through the C-ABI) vs the CPU oracle on seeded inputs.  Needs a MI355X."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet as UN
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from babe_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Fq,T,kh,kw,dil", [
+    (1, 8, 16, 64, 32, 5, 3, 1),
+    (2, 16, 16, 128, 16, 5, 3, 4),
+    (1, 64, 64, 64, 256, 5, 3, 2),
+    (1, 96, 96, 128, 64, 5, 3, 64),
+    (2, 2, 8, 64, 24, 1, 1, 1),
+    (1, 16, 2, 64, 40, 1, 1, 1),
+    (1, 2, 64, 192, 128, 5, 3, 1),
+    (1, 128, 256, 70, 100, 5, 3, 8),
+    (1, 256, 128, 64, 64, 1, 1, 1),
+])
+def test_conv2d_fwd_and_vjp(ops, B, Cin, Cout, Fq, T, kh, kw, dil):
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + T)
+    x = torch.randn(B, Cin, Fq, T, generator=g)
+    w = torch.randn(Cout, Cin, kh, kw, generator=g) / math.sqrt(Cin * kh * kw)
+    ref = UN.conv_same(x.double(), w.double(), dil)
+    pc = ops.PackedConv(w.cuda())
+    out = torch.empty(B, Cout, Fq, T, device="cuda")
+    ops.conv2d(x.cuda(), pc, out, dil=dil)
+    assert rel(out, ref) < 2e-6
+    # epilogue: alpha*acc*oscale + rbeta*res
+    res = torch.randn(B, Cout, Fq, T, generator=g)
+    osc = torch.randn(B, Cout, generator=g)
+    out2 = res.cuda().clone()
+    ops.conv2d(x.cuda(), pc, out2, dil=dil, res=out2, oscale=osc.cuda(), alpha=0.7, rbeta=0.3)
+    ref2 = 0.7 * ref * osc[:, :, None, None].double() + 0.3 * res.double()
+    assert rel(out2, ref2) < 2e-6
+    # input-VJP with per-channel input scale
+    gy = torch.randn(B, Cout, Fq, T, generator=g)
+    isc = torch.randn(B, Cout, generator=g)
+    xr = x.double().requires_grad_(True)
+    y = UN.conv_same(xr, w.double(), dil)
+    gref, = torch.autograd.grad((y * (gy * isc[:, :, None, None]).double()).sum(), xr)
+    gx = torch.empty(B, Cin, Fq, T, device="cuda")
+    ops.conv2d(gy.cuda(), pc, gx, dil=dil, transpose=True, in_scale=isc.cuda())
+    assert rel(gx, gref) < 2e-6
+
+
+def test_conv2d_two_sources_and_views(ops):
+    g = torch.Generator().manual_seed(5)
+    x1 = torch.randn(2, 16, 64, 32, generator=g)
+    x2 = torch.randn(2, 16, 64, 32, generator=g)
+    w = torch.randn(24, 32, 1, 1, generator=g) / 6
+    ref = UN.conv_same(torch.cat((x1, x2), 1).double(), w.double())
+    big = torch.zeros(2, 24, 128, 32, device="cuda")
+    pc = ops.PackedConv(w.cuda())
+    ops.conv2d(x1.cuda(), pc, big[:, :, 64:, :], x2=x2.cuda())
+    assert rel(big[:, :, 64:, :], ref) < 2e-6
+    assert float(big[:, :, :64, :].abs().max()) == 0.0
+    # input as a frequency sub-view
+    xin = torch.randn(2, 32, 128, 32, generator=g)
+    out = torch.empty(2, 24, 64, 32, device="cuda")
+    ops.conv2d(xin.cuda()[:, :, 64:, :], pc, out)
+    assert rel(out, UN.conv_same(xin[:, :, 64:, :].double(), w.double())) < 2e-6
+
+
+@pytest.mark.parametrize("B,C,Fq,T", [(2, 16, 64, 24), (1, 64, 128, 256), (1, 8, 5, 8)])
+def test_groupnorm_film_gelu_fwd_bwd(ops, B, C, Fq, T):
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(B, C, Fq, T, generator=g) * 1.7 + 0.4
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    film = 0.3 * torch.randn(B, C, generator=g)
+    xr = x.double().requires_grad_(True)
+    a_ref = F.gelu(UN.group_norm_nomean(xr, gamma.double().view(1, C, 1, 1)) * (film.double()[:, :, None, None] + 1))
+    xc = x.cuda()
+    stats, scale = ops.gn_scale(xc, gamma.cuda(), film.cuda())
+    a = ops.scale_gelu(xc, scale, torch.empty_like(xc))
+    assert rel(a, a_ref) < 2e-6
+    da = torch.randn(B, C, Fq, T, generator=g)
+    gy = torch.randn(B, C, Fq, T, generator=g)
+    gref, = torch.autograd.grad((a_ref * da.double()).sum(), xr)
+    gref = gref + 0.5 * gy.double()
+    dac = da.cuda()
+    gx = gy.cuda().clone()
+    ops.gn_bwd(xc, dac, gx, scale, stats, gx, 0.5)
+    assert rel(gx, gref) < 5e-6
+
+
+@pytest.mark.parametrize("T", [16, 22, 64, 600])
+def test_resample_fwd_and_adjoint(ops, T):
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(2, 3, 5, T, generator=g)
+    xc = x.cuda()
+    dn = ops.resample(xc, torch.empty(2, 3, 5, T // 2, device="cuda"), 0)
+    up = ops.resample(xc, torch.empty(2, 3, 5, 2 * T, device="cuda"), 1)
+    assert rel(dn, UN.resample_down(x.double())) < 1e-6
+    assert rel(up, UN.resample_up(x.double())) < 1e-6
+    for mode, fwd, To in ((2, UN.resample_down, T // 2), (3, UN.resample_up, 2 * T)):
+        gy = torch.randn(2, 3, 5, To, generator=g)
+        xr = x.double().requires_grad_(True)
+        gref, = torch.autograd.grad((fwd(xr) * gy.double()).sum(), xr)
+        gx = ops.resample(gy.cuda(), torch.empty(2, 3, 5, T, device="cuda"), mode)
+        assert rel(gx, gref) < 1e-6
+    # alpha/beta + strided output
+    big = torch.ones(2, 3, 9, T // 2, device="cuda")
+    ops.resample(xc, big[:, :, 4:, :], 0, alpha=2.0, beta=1.0)
+    assert rel(big[:, :, 4:, :], 2 * UN.resample_down(x.double()) + 1) < 1e-6
+    assert float((big[:, :, :4, :] - 1).abs().max()) == 0.0
+
+
+def test_axpby_linear_rff(ops):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 8, 40, generator=g)
+    big = torch.full((2, 3, 20, 40), 2.0, device="cuda")
+    ops.axpby(x.cuda(), big[:, :, 12:, :], alpha=0.5, beta=0.25)
+    assert rel(big[:, :, 12:, :], 0.5 * x + 0.5) < 1e-7
+    xm = torch.randn(2, 256, generator=g)
+    W = torch.randn(100, 256, generator=g)
+    bias = torch.randn(100, generator=g)
+    assert rel(ops.linear(xm.cuda(), W.cuda(), bias.cuda(), relu=True), torch.relu(xm @ W.t() + bias)) < 2e-6
+    cn = torch.tensor([[-2.3], [0.1]])
+    fr = 16 * torch.randn(1, 32, generator=g)
+    tab = 2 * math.pi * cn * fr
+    ref = torch.cat([torch.sin(tab), torch.cos(tab)], 1)
+    assert float((ops.rff(cn.cuda(), fr.cuda()).cpu() - ref).abs().max()) < 2e-4
