@@ -76,6 +76,43 @@ int babe_linear(const float* x, const float* W, const float* bias, float* out, i
 /* table = 2*pi*cnoise[b]*freq[j]; out[b] = [sin(table), cos(table)]  (:199-211) */
 int babe_rff(const float* cnoise, const float* freq, float* out, int B, int R, void* stream);
 
+/* ---- constant-Q transform (NSGT, mode "oct"): cqt_nsgt_pytorch.CQT_nsgt.fwd/.bwd/.apply_hpf_DC, call
+ * sites networks/cqtdiff+.py:743,841 and testing/blind_bwe_sampler.py:156.  The length-L real DFT is a
+ * four-step N1 x N2 transform whose two dense DFT stages run on babe_conv2d (1x1 convs with DFT matrices);
+ * the entry points below are the remaining pieces.  Spectra are planar: spec[b][0][k] = Re, spec[b][1][k] = Im,
+ * k = k1 + N1*k2 stored as [K2][N1] (natural order), KX = K2*N1 >= L/2+1. */
+/* forward: in [B][2*N1][N2] (Re rows k1 then Im rows) -> out [B][2*N2][N1] = transpose(in * tw[k1][n2]);
+ * adjoint=1: in [B][2*N2][N1] -> out [B][2*N1][N2] = transpose(in) * conj(tw). tw: [N1][N2] float2. */
+int babe_fft_twiddle_transpose(const float* in, float* out, const float* tw, int B, int N1, int N2,
+                               int adjoint, void* stream);
+typedef struct {
+    int nbands; int L; int KX;
+    const int* c;        /* [nbands] centre bin                               */
+    const int* M;        /* [nbands] window length                            */
+    const int* woff;     /* [nbands] offset of the band in the window tables  */
+    const int* log2T;    /* [nbands] log2 of the band's coefficient count     */
+    const int* oct;      /* [nbands] octave index (into coef[])               */
+    const int* binoct;   /* [nbands] bin index inside the octave              */
+    const float* tw4096; /* [2048] float2 exp(-2 pi i q/4096)                 */
+    int nocts; int binsoct;
+    float* coef[8];      /* per octave planar [B][2][binsoct][T_oct]          */
+} babe_cqt_bands;
+/* analysis-type: coef_k = IFFT_T(fold(spec[(c_k+m) mod L] * win[woff_k+m']))  (win carries 1/T and any scale).
+ * Used for CQT.fwd (win = g/T) and for the adjoint of CQT.bwd (win = (2/L) T^2 gd). */
+int babe_cqt_band_analysis(const babe_cqt_bands* bands, const float* spec, const float* win, int B, void* stream);
+/* synthesis-type: bs[b][woff_k+m'] = FFT_T(coef_k)[m mod T] * win[woff_k+m']  (float2).
+ * Used for CQT.bwd (win = T gd) and for the adjoint of CQT.fwd (win = g/T). */
+int babe_cqt_band_synthesis(const babe_cqt_bands* bands, float* bs, const float* win, long bs_stride, int B,
+                            void* stream);
+/* spec[b][:, n] = scale * sum over CSR entries of n of bs (conjugated when the entry's sign bit is set);
+ * optionally multiplied by mul[n] (real, e.g. the DC/Nyquist high-pass) ; n > L/2 -> 0. */
+int babe_cqt_gather(const float* bs, long bs_stride, const int* rowptr, const int* src, float* spec, int KX,
+                    int L, float scale, const float* mul, int B, void* stream);
+/* spec_out = spec_in * mul[n] * scale for n <= L/2, 0 above (apply_hpf_DC in the frequency domain);
+ * optional second term: spec_out += spec2 * mul[n] * scale2. */
+int babe_spec_scale(const float* spec_in, const float* spec2, float* spec_out, const float* mul, int KX, int L,
+                    float scale, float scale2, int B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

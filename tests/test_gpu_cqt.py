@@ -1,0 +1,83 @@
+"""HIP CQT (four-step DFT on the MFMA conv kernel + LDS band FFTs) vs the oracle NSGT.  Needs a MI355X."""
+import pytest
+import torch
+
+from oracle.nsgt import CQT_nsgt as OracleCQT
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module", params=[(22050, 92092), (44100, 368368)])
+def pair(request):
+    from babe_amd.cqt import CQT_nsgt
+    fs, L = request.param
+    return CQT_nsgt(7, 64, "oct", ("kaiser", 1), fs, L, device="cuda"), OracleCQT(7, 64, "oct", ("kaiser", 1), fs, L, dtype=torch.float64)
+
+
+def test_rfft_and_transpose(pair):
+    hip, _ = pair
+    L = hip.Ls
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, L, generator=g)
+    spec = hip.fft.rfft(x.cuda())
+    ref = torch.fft.rfft(x.double())
+    got = torch.complex(spec[:, 0, : L // 2 + 1].double().cpu(), spec[:, 1, : L // 2 + 1].double().cpu())
+    assert float((got - ref).abs().max() / ref.abs().max()) < 5e-6
+    # transpose: <rfft x, G> == <x, rfft_T G>
+    G = torch.zeros(2, 2, hip.fft.KX)
+    G[:, :, : L // 2 + 1] = torch.randn(2, 2, L // 2 + 1, generator=g)
+    xt = hip.fft.rfft_T(G.cuda())
+    lhs = float((spec.double().cpu() * G.double()).sum())
+    rhs = float((x.double() * xt.double().cpu()).sum())
+    assert abs(lhs - rhs) < 2e-5 * (abs(lhs) + abs(rhs) + 1e3)
+
+
+def test_fwd_bwd_hpf_vs_oracle(pair):
+    hip, orc = pair
+    L = hip.Ls
+    g = torch.Generator().manual_seed(2)
+    x = 0.1 * torch.randn(2, L, generator=g)
+    co = hip.fwd_planar(x.cuda())
+    ref = orc.fwd(x.double().unsqueeze(1))
+    assert [c.shape[-1] for c in co] == [r.shape[-1] for r in ref]
+    for c, r in zip(co, ref):
+        got = torch.complex(c[:, 0].double().cpu(), c[:, 1].double().cpu())
+        assert float((got - r.squeeze(1)).abs().max() / r.abs().max()) < 2e-5
+    # synthesis of arbitrary coefficients
+    cs = [torch.randn(2, 2, 64, T, generator=g) for T in hip.T_oct]
+    y = hip.bwd_planar([c.cuda() for c in cs])
+    yref = orc.bwd([torch.complex(c[:, 0].double(), c[:, 1].double()).unsqueeze(1) for c in cs]).squeeze(1)
+    assert rel(y, yref) < 2e-5
+    # perfect reconstruction == high-pass
+    xr = hip.bwd_planar(co)
+    xh = hip.apply_hpf_DC(x.cuda())
+    assert rel(xh, orc.apply_hpf_DC(x.double())) < 2e-5
+    assert rel(xr, xh) < 2e-5
+    # reference-style complex API
+    cl = hip.fwd(x.cuda().unsqueeze(1))
+    assert cl[0].shape == (2, 1, 64, hip.T_oct[0]) and cl[0].is_complex()
+    assert rel(hip.bwd(cl).squeeze(1), xh) < 2e-5
+
+
+def test_adjoints(pair):
+    hip, _ = pair
+    L = hip.Ls
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, L, generator=g).cuda()
+    G = [torch.randn(1, 2, 64, T, generator=g).cuda() for T in hip.T_oct]
+    co = hip.fwd_planar(x)
+    lhs = sum(float((c.double() * gg.double()).sum()) for c, gg in zip(co, G))
+    rhs = float((x.double() * hip.fwd_adjoint(G).double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * (abs(lhs) + abs(rhs)) + 1e-3
+    y = hip.bwd_planar(G)
+    gy = torch.randn(1, L, generator=g).cuda()
+    gco = hip.bwd_adjoint(gy)
+    lhs = float((y.double() * gy.double()).sum())
+    rhs = sum(float((c.double() * gg.double()).sum()) for c, gg in zip(gco, G))
+    assert abs(lhs - rhs) < 1e-4 * (abs(lhs) + abs(rhs)) + 1e-3

@@ -137,3 +137,34 @@ def test_axpby_linear_rff(ops):
     tab = 2 * math.pi * cn * fr
     ref = torch.cat([torch.sin(tab), torch.cos(tab)], 1)
     assert float((ops.rff(cn.cuda(), fr.cuda()).cpu() - ref).abs().max()) < 2e-4
+
+
+def test_unet_body_fwd_and_vjp_small():
+    """UNet body (between CQT.fwd and CQT.bwd) on the HIP engine vs the oracle with autograd."""
+    import os
+    import numpy as np
+    from babe_amd.networks.unet_engine import UnetEngine
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(G, "unet_small.npz")).items()}
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    cfg = dict(num_octs=7, bins_per_oct=64, num_dils=[2, 3, 4, 5, 6, 7, 7])
+    Ns = [8, 8, 8, 8, 16, 16, 16]
+    gen = torch.Generator().manual_seed(31)
+    B = 2
+    Ts = [16 * 2 ** j for j in range(7)]
+    C_list = [torch.randn(B, 2, 64, T, generator=gen) for T in Ts]
+    cn = torch.tensor([[-0.4], [-1.1]])
+    Cr = [c.double().requires_grad_(True) for c in C_list]
+    sdd = {k: v.double() for k, v in sd.items()}
+    emb = UN.embedding(sdd, cn.double())
+    outs_ref = UN.unet_body(sdd, cfg, Cr, emb)
+    gouts = [torch.randn(o.shape, generator=gen) for o in outs_ref]
+    grefs = torch.autograd.grad(sum((o * go.double()).sum() for o, go in zip(outs_ref, gouts)), Cr)
+    eng = UnetEngine({k: v.cuda().float() for k, v in sd.items()}, Ns, cfg["num_dils"])
+    film = eng.embed(cn.cuda())
+    outs = eng.forward([c.cuda() for c in C_list], film)
+    for o, r in zip(outs, outs_ref):
+        assert rel(o, r) < 2e-5
+    gC = eng.vjp([go.cuda() for go in gouts])
+    for a, r in zip(gC, grefs):
+        assert rel(a, r) < 1e-4
