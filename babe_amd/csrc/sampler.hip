@@ -1,0 +1,87 @@
+// Element-wise steps of the guided EDM sampler (testing/blind_bwe_sampler.py:503-516, :125-135, :701-761;
+// diff_params/edm.py:144-159).  Trivially HBM-bound: float4 streaming, double partial sums.
+#include "common.h"
+#include "../../include/babe_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void lincomb3_kernel(float* __restrict__ out, float a, const float* __restrict__ x,
+                                                       float b, const float* __restrict__ y, float c,
+                                                       const float* __restrict__ z, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = a * x[i];
+        if (y) v += b * y[i];
+        if (z) v += c * z[i];
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long g_bs,
+                                                            double* __restrict__ part, int nblk, long n) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    const float* p = g + (long)b * g_bs;
+    double acc = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double v = p[i];
+        acc += v * v;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void score_direction_kernel(const float* __restrict__ xden,
+                                                              const float* __restrict__ xhat,
+                                                              const float* __restrict__ g,
+                                                              const double* __restrict__ part, int nblk,
+                                                              float* __restrict__ d, float t, float xi,
+                                                              float sqrt_len, int shared_norm, int B, long n) {
+    const int b = blockIdx.y;
+    double s2 = 0;
+    if (shared_norm) {
+        for (int i = 0; i < B * nblk; ++i) s2 += part[i];
+    } else {
+        for (int i = 0; i < nblk; ++i) s2 += part[(long)b * nblk + i];
+    }
+    const float normguide = (float)sqrt(s2) / sqrt_len;
+    const float s = xi / (normguide + 1e-6f);
+    const float it2 = 1.f / (t * t);
+    const long base = (long)b * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float score = (xden[base + i] - xhat[base + i]) * it2 - s * g[base + i] / t;
+        d[base + i] = -t * score;
+    }
+}
+
+}  // namespace
+
+extern "C" int babe_lincomb3(float* out, float a, const float* x, float b, const float* y, float c, const float* z,
+                             long n, void* stream) {
+    BABE_CHECK_ARG(out && x && n > 0, "lincomb3: bad arguments");
+    int bx = cdiv(n, 1024);
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(lincomb3_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, out, a, x, b, y, c, z, n);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_sumsq_partial(const float* g, long g_bs, double* part, int nblk, int B, long n, void* stream) {
+    BABE_CHECK_ARG(g && part && nblk > 0 && B > 0 && n > 0, "sumsq_partial: bad arguments");
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, g, g_bs, part, nblk, n);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_score_direction(const float* xden, const float* xhat, const float* g, const double* part, int nblk,
+                                    float* d, float t, float xi, float audio_len, int shared_norm, int B, long n,
+                                    void* stream) {
+    BABE_CHECK_ARG(xden && xhat && g && part && d && B > 0 && n > 0 && t > 0, "score_direction: bad arguments");
+    int bx = cdiv(n, 1024);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(score_direction_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, xden, xhat, g, part,
+                       nblk, d, t, xi, sqrtf(audio_len), shared_norm, B, n);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}

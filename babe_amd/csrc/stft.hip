@@ -1,0 +1,423 @@
+// STFT-domain degradation model of blind BWE on gfx950: STFT, filter + iSTFT, overlap-add / residual,
+// per-bin magnitude statistics, piecewise-log low-pass design and the projected-GD filter fit.
+// Reference: /root/reference/utils/blind_bwe_utils.py:6-39, :82-119, :250-296 and
+// /root/reference/testing/blind_bwe_sampler.py:518-595.  HBM/latency-bound; the 4096-point FFT of
+// a frame lives in LDS (fft_lds.h); the fit runs as ONE workgroup per clip on 3x2049 doubles.
+#include "common.h"
+#include "fft_lds.h"
+#include "../../include/babe_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float hamming_periodic(int i, int n) {
+    // torch.hamming_window(n) (periodic): 0.54 - 0.46 cos(2 pi i / n)
+    return 0.54f - 0.46f * cospif(2.0f * (float)i / (float)n);
+}
+
+// grid (frames, B), 256 threads
+__global__ __launch_bounds__(256) void stft_fwd_kernel(const float* __restrict__ x, long x_bs, int L,
+                                                       const float* __restrict__ pre, float* __restrict__ spec,
+                                                       int log2n, int frames, const float2* __restrict__ tw) {
+    __shared__ float2 a[4096];
+    const int n = 1 << log2n, hop = n >> 1;
+    const int t = blockIdx.x, b = blockIdx.y;
+    const float* xb = x + (long)b * x_bs;
+    const int s0 = t * hop;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int s = s0 + i;
+        float v = (s < L) ? xb[s] : 0.f;
+        if (pre) v *= pre[s];
+        a[bitrev_n(i, log2n)] = make_float2(v * hamming_periodic(i, n), 0.f);
+    }
+    fft_lds_inplace(a, log2n, tw, -1);
+    const int nb = hop + 1;
+    float2* o = reinterpret_cast<float2*>(spec) + ((long)b * frames + t) * nb;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) o[k] = a[k];
+}
+
+__global__ __launch_bounds__(256) void spec_filter_istft_kernel(const float* __restrict__ spec,
+                                                                const float* __restrict__ H, long H_bs,
+                                                                float* __restrict__ fr, int log2n, int frames,
+                                                                const float2* __restrict__ tw) {
+    __shared__ float2 a[4096];
+    const int n = 1 << log2n, hop = n >> 1;
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int nb = hop + 1;
+    const float2* s = reinterpret_cast<const float2*>(spec) + ((long)b * frames + t) * nb;
+    const float* Hb = H + (long)b * H_bs;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        float2 v = s[k];
+        const float h = Hb[k];
+        v.x *= h;
+        v.y *= h;
+        if (k == 0 || k == hop) {
+            a[bitrev_n(k, log2n)] = make_float2(v.x, 0.f);          // irfft ignores Im at DC / Nyquist
+        } else {
+            a[bitrev_n(k, log2n)] = v;
+            a[bitrev_n(n - k, log2n)] = make_float2(v.x, -v.y);
+        }
+    }
+    fft_lds_inplace(a, log2n, tw, +1);
+    float* o = fr + ((long)b * frames + t) * n;
+    const float inv = 1.f / (float)n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = a[i].x * inv * hamming_periodic(i, n);
+}
+
+// grid (nblk, B)
+__global__ __launch_bounds__(256) void ola_kernel(const float* __restrict__ fr, const float* __restrict__ post,
+                                                  const float* __restrict__ y, long y_bs, float* __restrict__ out,
+                                                  long out_bs, double* __restrict__ part, int nblk, int L, int n,
+                                                  int frames) {
+    __shared__ double sh[8];
+    const int b = blockIdx.y;
+    const int hop = n >> 1;
+    const float* f = fr + (long)b * frames * n;
+    double acc = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long)gridDim.x * blockDim.x) {
+        const int t1 = (int)(i / hop);                 // latest frame containing sample i
+        float v = 0.f;
+        if (t1 < frames) v += f[(long)t1 * n + (i - (long)t1 * hop)];
+        if (t1 >= 1 && t1 - 1 < frames) v += f[(long)(t1 - 1) * n + (i - (long)(t1 - 1) * hop)];
+        if (post) v *= post[i];
+        if (y) {
+            v = y[(long)b * y_bs + i] - v;
+            acc += (double)v * v;
+        }
+        out[(long)b * out_bs + i] = v;
+    }
+    if (part) {
+        acc = wave_sum(acc);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) sh[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void residual_seed_kernel(const float* __restrict__ r, long r_bs,
+                                                            const double* __restrict__ part, int nblk,
+                                                            const float* __restrict__ post, float* __restrict__ out,
+                                                            long out_bs, int L) {
+    const int b = blockIdx.y;
+    double s = 0;
+    for (int i = 0; i < nblk; ++i) s += part[(long)b * nblk + i];
+    const float inv = (s > 0) ? (float)(-1.0 / sqrt(s)) : 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long)gridDim.x * blockDim.x) {
+        float v = r[(long)b * r_bs + i] * inv;
+        if (post) v *= post[i];
+        out[(long)b * out_bs + i] = v;
+    }
+}
+
+// grid (ceil(nbins/256), Bout): threads over bins, loop over frames (and batch if shared)
+__global__ __launch_bounds__(256) void mag_stats_kernel(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                        double* __restrict__ stats, int B, int nbins, int frames,
+                                                        int shared) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nbins) return;
+    const int bo = blockIdx.y;
+    const int b0 = shared ? 0 : bo, b1 = shared ? B : bo + 1;
+    double sxx = 0, sxy = 0, syy = 0;
+    for (int b = b0; b < b1; ++b) {
+        const float2* X = reinterpret_cast<const float2*>(sx) + (long)b * frames * nbins;
+        const float2* Y = reinterpret_cast<const float2*>(sy) + (long)b * frames * nbins;
+        for (int t = 0; t < frames; ++t) {
+            const float2 xv = X[(long)t * nbins + k], yv = Y[(long)t * nbins + k];
+            const float mx = sqrtf(xv.x * xv.x + xv.y * xv.y);
+            const float my = sqrtf(yv.x * yv.x + yv.y * yv.y);
+            sxx += (double)mx * mx;
+            sxy += (double)mx * my;
+            syy += (double)my * my;
+        }
+    }
+    stats[((long)bo * 3 + 0) * nbins + k] = sxx;
+    stats[((long)bo * 3 + 1) * nbins + k] = sxy;
+    stats[((long)bo * 3 + 2) * nbins + k] = syy;
+}
+
+constexpr int KMAX = 8;
+
+struct Filt {
+    float fc[KMAX], A[KMAX], anchor[KMAX];
+    int kstar[KMAX];
+};
+
+// first bin whose float32 frequency is >= fc (exact float32 comparisons like `f >= fc` in the reference)
+__device__ int first_bin_ge(float fc, float df, int nbins) {
+    int k = (int)floorf(fc / df);
+    if (k < 0) k = 0;
+    if (k > nbins - 1) k = nbins - 1;
+    while (k > 0 && (float)(k - 1) * df >= fc) --k;
+    while (k < nbins && (float)k * df < fc) ++k;
+    return k;                                       // == nbins when no bin qualifies
+}
+
+__device__ __forceinline__ float seg_val(float f, float fc, float A) {
+    // 10 ** (A * log2(f / fc) / 20) in float32, same operation order as the reference
+    return powf(10.f, A * log2f(f / fc) / 20.f);
+}
+
+// serial anchor chain (K <= 8): anchor_i = value written by segment i-1 at the first bin >= fc_i
+__device__ void build_filter(Filt& F, int K, float df, int nbins) {
+    F.anchor[0] = 1.f;
+    F.kstar[0] = first_bin_ge(F.fc[0], df, nbins);
+    for (int i = 1; i < K; ++i) {
+        const int ks = first_bin_ge(F.fc[i], df, nbins);
+        F.kstar[i] = ks;
+        const float fk = (float)(ks < nbins ? ks : nbins - 1) * df;
+        // the bin may sit below fc_{i-1}'s first bin only if fc is unsorted; then H there is still the older value
+        int j = i - 1;
+        while (j > 0 && fk < F.fc[j]) --j;
+        float v;
+        if (fk < F.fc[j]) v = 1.f;
+        else v = seg_val(fk, F.fc[j], F.A[j]) * F.anchor[j];
+        F.anchor[i] = v;
+    }
+}
+
+__device__ __forceinline__ int seg_of(const Filt& F, int K, float f) {
+    int s = -1;
+    for (int i = 0; i < K; ++i)
+        if (f >= F.fc[i]) s = i;                    // later breakpoints overwrite earlier ones
+    return s;
+}
+
+__global__ __launch_bounds__(256) void design_filter_kernel(const float* __restrict__ params, float* __restrict__ H,
+                                                            int K, int nbins, float df) {
+    __shared__ Filt F;
+    const int p = blockIdx.x;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < K; ++i) {
+            F.fc[i] = params[((long)p * 2 + 0) * K + i];
+            F.A[i] = params[((long)p * 2 + 1) * K + i];
+        }
+        build_filter(F, K, df, nbins);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
+        const float f = (float)k * df;
+        const int s = seg_of(F, K, f);
+        H[(long)p * nbins + k] = (s < 0) ? 1.f : seg_val(f, F.fc[s], F.A[s]) * F.anchor[s];
+    }
+}
+
+__device__ __forceinline__ float weight_sq(int k, int nbins, int kind) {
+    const float fr = (float)k / (float)(nbins - 1);          // torch.linspace(0,1,nbins)[k]
+    float w;
+    switch (kind) {
+        case 1: w = sqrtf(fr); break;
+        case 2: w = fr; break;
+        case 3: w = log2f(1.f + fr); break;
+        default: w = 1.f;
+    }
+    return w * w;
+}
+
+// one block per clip
+__global__ __launch_bounds__(256) void filter_fit_kernel(const double* __restrict__ stats, float* __restrict__ params,
+                                                         int* __restrict__ n_iter, int K, int nbins, float df,
+                                                         babe_fit_cfg cfg) {
+    __shared__ Filt F;
+    __shared__ double red[4][2 * KMAX + 1];
+    __shared__ float prev[2 * KMAX];
+    __shared__ int done;
+    const int p = blockIdx.x;
+    const double* Sxx = stats + ((long)p * 3 + 0) * nbins;
+    const double* Sxy = stats + ((long)p * 3 + 1) * nbins;
+    const double* Syy = stats + ((long)p * 3 + 2) * nbins;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < K; ++i) {
+            F.fc[i] = params[((long)p * 2 + 0) * K + i];
+            F.A[i] = params[((long)p * 2 + 1) * K + i];
+        }
+        done = 0;
+    }
+    int it = 0;
+    const double cln = 0.11512925464970228;   // ln(10)/20
+    for (; it < cfg.max_iter; ++it) {
+        __syncthreads();
+        if (threadIdx.x == 0) build_filter(F, K, df, nbins);
+        __syncthreads();
+        double E[KMAX], Ep[KMAX], loss2 = 0;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) E[i] = Ep[i] = 0;
+        for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
+            const float f = (float)k * df;
+            const int s = seg_of(F, K, f);
+            const double w2 = weight_sq(k, nbins, cfg.weighting);
+            double Hk = 1.0, lg = 0.0;
+            if (s >= 0) {
+                Hk = (double)(seg_val(f, F.fc[s], F.A[s]) * F.anchor[s]);
+                lg = (double)log2f(f / F.fc[s]);
+            }
+            loss2 += w2 * (Hk * Hk * Sxx[k] - 2.0 * Hk * Sxy[k] + Syy[k]);
+            if (s >= 0) {
+                const double e = w2 * (Hk * Sxx[k] - Sxy[k]) * Hk * cln;
+#pragma unroll
+                for (int i = 0; i < KMAX; ++i)
+                    if (i == s) {
+                        E[i] += e;
+                        Ep[i] += e * lg;
+                    }
+            }
+        }
+        loss2 = wave_sum(loss2);
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            E[i] = wave_sum(E[i]);
+            Ep[i] = wave_sum(Ep[i]);
+        }
+        if (lane == 0) {
+            red[wave][0] = loss2;
+            for (int i = 0; i < KMAX; ++i) {
+                red[wave][1 + i] = E[i];
+                red[wave][1 + KMAX + i] = Ep[i];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double l2 = 0, Et[KMAX], Ept[KMAX];
+            for (int i = 0; i < KMAX; ++i) Et[i] = Ept[i] = 0;
+            for (int w = 0; w < 4; ++w) {
+                l2 += red[w][0];
+                for (int i = 0; i < KMAX; ++i) {
+                    Et[i] += red[w][1 + i];
+                    Ept[i] += red[w][1 + KMAX + i];
+                }
+            }
+            const double loss = sqrt(l2 > 0 ? l2 : 0);
+            const double il = loss > 0 ? 1.0 / loss : 0.0;
+            // suffix sums of E
+            double suf[KMAX + 1];
+            suf[K] = 0;
+            for (int i = K - 1; i >= 0; --i) suf[i] = suf[i + 1] + Et[i];
+            float nfc[KMAX], nA[KMAX];
+            for (int j = 0; j < K; ++j) {
+                double Lj = 0;
+                if (j + 1 < K) {
+                    const int ks = F.kstar[j + 1] < nbins ? F.kstar[j + 1] : nbins - 1;
+                    Lj = (double)log2f(((float)ks * df) / F.fc[j]);
+                }
+                const double gA = (Ept[j] + Lj * suf[j + 1]) * il;
+                const double gfc = -(double)F.A[j] / ((double)F.fc[j] * 0.6931471805599453) * suf[j] * il;
+                nfc[j] = F.fc[j] - cfg.mu_fc * (float)gfc;
+                nA[j] = F.A[j] - cfg.mu_A * (float)gA;
+            }
+            if (cfg.clamp_fc) {
+                nfc[0] = fminf(fmaxf(nfc[0], cfg.fcmin), cfg.fcmax);
+                for (int j = 1; j < K; ++j) nfc[j] = fminf(fmaxf(nfc[j], nfc[j - 1] + 1.f), cfg.fcmax);
+            }
+            if (cfg.clamp_A) {
+                nA[0] = fminf(fmaxf(nA[0], cfg.Amin), cfg.only_negative_A ? -1.f : cfg.Amax);
+                for (int j = 1; j < K; ++j)
+                    nA[j] = fminf(fmaxf(nA[j], cfg.Amin), cfg.only_negative_A ? nA[j - 1] : cfg.Amax);
+            }
+            if (it > 0) {
+                float dfc = 0, dA = 0;
+                for (int j = 0; j < K; ++j) {
+                    dfc += fabsf(nfc[j] - prev[j]);
+                    dA += fabsf(nA[j] - prev[KMAX + j]);
+                }
+                if (dfc / K < cfg.tol_fc && dA / K < cfg.tol_A) done = 1;
+            }
+            for (int j = 0; j < K; ++j) {
+                F.fc[j] = nfc[j];
+                F.A[j] = nA[j];
+                prev[j] = nfc[j];
+                prev[KMAX + j] = nA[j];
+            }
+        }
+        __syncthreads();
+        if (done) {
+            ++it;
+            break;
+        }
+    }
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < K; ++i) {
+            params[((long)p * 2 + 0) * K + i] = F.fc[i];
+            params[((long)p * 2 + 1) * K + i] = F.A[i];
+        }
+        if (n_iter) n_iter[p] = it;
+    }
+}
+
+int ilog2_exact(int n) {
+    int l = 0;
+    while ((1 << l) < n) ++l;
+    return (1 << l) == n ? l : -1;
+}
+
+}  // namespace
+
+extern "C" int babe_stft_fwd(const float* x, long x_bs, int L, const float* pre, float* spec, int B, int nfft,
+                             int frames, const float* tw4096, void* stream) {
+    const int lg = ilog2_exact(nfft);
+    BABE_CHECK_ARG(x && spec && tw4096 && B > 0 && L > 0, "stft_fwd: bad arguments");
+    BABE_CHECK_ARG(lg >= 8 && lg <= 12, "stft_fwd: nfft=%d unsupported (256..4096, power of two)", nfft);
+    BABE_CHECK_ARG(frames == 1 + L / (nfft / 2), "stft_fwd: frames=%d inconsistent with L=%d", frames, L);
+    hipLaunchKernelGGL(stft_fwd_kernel, dim3(frames, B), dim3(256), 0, (hipStream_t)stream, x, x_bs, L, pre, spec, lg,
+                       frames, reinterpret_cast<const float2*>(tw4096));
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_spec_filter_istft(const float* spec, const float* H, long H_bs, float* frames_out, int B, int nfft,
+                                      int frames, const float* tw4096, void* stream) {
+    const int lg = ilog2_exact(nfft);
+    BABE_CHECK_ARG(spec && H && frames_out && tw4096 && B > 0 && frames > 0, "spec_filter_istft: bad arguments");
+    BABE_CHECK_ARG(lg >= 8 && lg <= 12, "spec_filter_istft: nfft=%d unsupported", nfft);
+    hipLaunchKernelGGL(spec_filter_istft_kernel, dim3(frames, B), dim3(256), 0, (hipStream_t)stream, spec, H, H_bs,
+                       frames_out, lg, frames, reinterpret_cast<const float2*>(tw4096));
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_ola(const float* frames_in, const float* post, const float* y, long y_bs, float* out, long out_bs,
+                        double* part, int nblk, int B, int L, int nfft, int frames, void* stream) {
+    BABE_CHECK_ARG(frames_in && out && B > 0 && L > 0 && nblk > 0, "ola: bad arguments");
+    BABE_CHECK_ARG(!y || part, "ola: residual mode needs a partial-sum buffer");
+    hipLaunchKernelGGL(ola_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, frames_in, post, y, y_bs, out,
+                       out_bs, y ? part : nullptr, nblk, L, nfft, frames);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_residual_seed(const float* r, long r_bs, const double* part, int nblk, const float* post,
+                                  float* out, long out_bs, int B, int L, void* stream) {
+    BABE_CHECK_ARG(r && part && out && B > 0 && L > 0, "residual_seed: bad arguments");
+    int bx = cdiv(L, 1024);
+    hipLaunchKernelGGL(residual_seed_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, r, r_bs, part, nblk, post,
+                       out, out_bs, L);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_stft_mag_stats(const float* specX, const float* specY, double* stats, int B, int nbins, int frames,
+                                   int shared, void* stream) {
+    BABE_CHECK_ARG(specX && specY && stats && B > 0 && nbins > 1 && frames > 0, "stft_mag_stats: bad arguments");
+    hipLaunchKernelGGL(mag_stats_kernel, dim3(cdiv(nbins, 256), shared ? 1 : B), dim3(256), 0, (hipStream_t)stream,
+                       specX, specY, stats, B, nbins, frames, shared);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_design_filter(const float* params, float* H, int P, int K, int nbins, float fs, int nfft,
+                                  void* stream) {
+    BABE_CHECK_ARG(params && H && P > 0 && K > 0 && K <= KMAX && nbins > 1, "design_filter: bad arguments (K<=8)");
+    const float df = fs / (float)nfft;
+    hipLaunchKernelGGL(design_filter_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, params, H, K, nbins, df);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_filter_fit(const double* stats, float* params, int* n_iter, int P, int K, int nbins, float fs,
+                               int nfft, const babe_fit_cfg* cfg, void* stream) {
+    BABE_CHECK_ARG(stats && params && cfg && P > 0 && K > 0 && K <= KMAX && nbins > 1, "filter_fit: bad arguments");
+    const float df = fs / (float)nfft;
+    hipLaunchKernelGGL(filter_fit_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, stats, params, n_iter, K, nbins,
+                       df, *cfg);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}

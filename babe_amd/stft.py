@@ -1,0 +1,157 @@
+"""STFT-domain degradation model on the babe_hip kernels (host wrappers).
+
+Mirrors /root/reference/utils/blind_bwe_utils.py (apply_stft :15-26, apply_filter :6-13,
+apply_filter_istft :28-39, design_filter :82-119, apply_filter_and_norm_STFTmag_fweighted :250-296)
+and BlindSampler.fit_params (/root/reference/testing/blind_bwe_sampler.py:533-595).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from ._lib import check, lib, ptr, stream
+
+_WEIGHTS = {"None": 0, "sqrt": 1, "linear": 2, "log": 3}
+
+
+class FitCfg(C.Structure):
+    _fields_ = [("mu_fc", C.c_float), ("mu_A", C.c_float), ("tol_fc", C.c_float), ("tol_A", C.c_float),
+                ("fcmin", C.c_float), ("fcmax", C.c_float), ("Amin", C.c_float), ("Amax", C.c_float),
+                ("max_iter", C.c_int), ("clamp_fc", C.c_int), ("clamp_A", C.c_int), ("only_negative_A", C.c_int),
+                ("weighting", C.c_int)]
+
+
+_registered = False
+
+
+def _register():
+    global _registered
+    if _registered:
+        return
+    L = lib()
+    P, I, F, Lg = C.c_void_p, C.c_int, C.c_float, C.c_long
+    sig = {
+        "babe_stft_fwd": [P, Lg, I, P, P, I, I, I, P, P],
+        "babe_spec_filter_istft": [P, P, Lg, P, I, I, I, P, P],
+        "babe_ola": [P, P, P, Lg, P, Lg, P, I, I, I, I, I, P],
+        "babe_residual_seed": [P, Lg, P, I, P, P, Lg, I, I, P],
+        "babe_stft_mag_stats": [P, P, P, I, I, I, I, P],
+        "babe_design_filter": [P, P, I, I, I, F, I, P],
+        "babe_filter_fit": [P, P, P, I, I, I, F, I, C.POINTER(FitCfg), P],
+        "babe_lincomb3": [P, F, P, F, P, F, P, Lg, P],
+        "babe_sumsq_partial": [P, Lg, P, I, I, Lg, P],
+        "babe_score_direction": [P, P, P, P, I, P, F, F, F, I, I, Lg, P],
+    }
+    for n, s in sig.items():
+        fn = getattr(L, n)
+        fn.argtypes = s
+        fn.restype = C.c_int
+    _registered = True
+
+
+def lincomb(out, a, x, b=0.0, y=None, c=0.0, z=None):
+    _register()
+    n = x.numel()
+    assert x.is_contiguous() and out.is_contiguous() and (y is None or y.is_contiguous()) and (z is None or z.is_contiguous())
+    check(lib().babe_lincomb3(ptr(out), a, ptr(x), b, ptr(y), c, ptr(z), n, stream()), "lincomb3")
+    return out
+
+
+class STFTOps:
+    """Plan for one (nfft, L, fs): window-envelope table, FFT twiddles, scratch."""
+
+    NBLK = 64
+
+    def __init__(self, nfft, L, fs, device):
+        _register()
+        self.nfft, self.L, self.fs, self.dev = int(nfft), int(L), float(fs), torch.device(device)
+        self.hop = self.nfft // 2
+        self.frames = 1 + self.L // self.hop
+        self.nbins = self.hop + 1
+        q = np.arange(2048, dtype=np.float64)
+        self.tw4096 = torch.tensor(np.stack([np.cos(2 * np.pi * q / 4096), -np.sin(2 * np.pi * q / 4096)], -1),
+                                   dtype=torch.float32, device=self.dev).contiguous()
+        w = torch.hamming_window(self.nfft, dtype=torch.float32)           # periodic, like the reference (:19)
+        ntot = self.nfft + self.hop * (self.frames - 1)
+        env = torch.zeros(ntot, dtype=torch.float32)
+        for t in range(self.frames):
+            env[t * self.hop: t * self.hop + self.nfft] += w * w
+        self.env_inv = (1.0 / env).to(self.dev)
+        self.freqs = torch.fft.rfftfreq(self.nfft, d=1 / fs).to(self.dev)
+
+    # -- kernels
+    def stft(self, x):
+        B = x.shape[0]
+        assert x.shape[1] == self.L and x.stride(1) == 1
+        spec = torch.empty(B, self.frames, self.nbins, 2, device=self.dev)
+        check(lib().babe_stft_fwd(ptr(x), x.stride(0), self.L, None, ptr(spec), B, self.nfft, self.frames,
+                                  ptr(self.tw4096), stream()), "stft_fwd")
+        return spec
+
+    def filter_frames(self, spec, H):
+        """H: [nbins] (shared) or [B,nbins]."""
+        B = spec.shape[0]
+        fr = torch.empty(B, self.frames, self.nfft, device=self.dev)
+        H_bs = 0 if H.dim() == 1 else H.stride(0)
+        check(lib().babe_spec_filter_istft(ptr(spec), ptr(H), H_bs, ptr(fr), B, self.nfft, self.frames,
+                                           ptr(self.tw4096), stream()), "spec_filter_istft")
+        return fr
+
+    def ola(self, fr, normalise, y=None):
+        """Returns overlap-add (cropped to L) or, with y, (residual y-ola, partial sums of squares)."""
+        B = fr.shape[0]
+        out = torch.empty(B, self.L, device=self.dev)
+        part = torch.empty(B, self.NBLK, device=self.dev, dtype=torch.float64) if y is not None else None
+        check(lib().babe_ola(ptr(fr), ptr(self.env_inv) if normalise else None, ptr(y), y.stride(0) if y is not None else 0,
+                             ptr(out), out.stride(0), ptr(part), self.NBLK, B, self.L, self.nfft, self.frames, stream()), "ola")
+        return (out, part) if y is not None else out
+
+    def residual_seed(self, r, part):
+        B = r.shape[0]
+        out = torch.empty_like(r)
+        check(lib().babe_residual_seed(ptr(r), r.stride(0), ptr(part), self.NBLK, ptr(self.env_inv), ptr(out),
+                                       out.stride(0), B, self.L, stream()), "residual_seed")
+        return out
+
+    def mag_stats(self, specX, specY, shared=False):
+        B = specX.shape[0]
+        stats = torch.empty(1 if shared else B, 3, self.nbins, device=self.dev, dtype=torch.float64)
+        check(lib().babe_stft_mag_stats(ptr(specX), ptr(specY), ptr(stats), B, self.nbins, self.frames, int(shared),
+                                        stream()), "stft_mag_stats")
+        return stats
+
+    def design_filter(self, params):
+        """params [2,K] or [P,2,K] -> H [nbins] or [P,nbins]."""
+        single = params.dim() == 2
+        p = (params.unsqueeze(0) if single else params).contiguous().float()
+        P_, _, K = p.shape
+        H = torch.empty(P_, self.nbins, device=self.dev)
+        check(lib().babe_design_filter(ptr(p), ptr(H), P_, K, self.nbins, self.fs, self.nfft, stream()), "design_filter")
+        return H[0] if single else H
+
+    def filter_fit(self, stats, params, cfg):
+        """params [P,2,K] float32 device, updated in place. Returns n_iter [P] int32."""
+        P_, _, K = params.shape
+        assert params.is_contiguous() and stats.shape[0] == P_
+        nit = torch.empty(P_, dtype=torch.int32, device=self.dev)
+        check(lib().babe_filter_fit(ptr(stats), ptr(params), ptr(nit), P_, K, self.nbins, self.fs, self.nfft,
+                                    C.byref(cfg), stream()), "filter_fit")
+        return nit
+
+    # -- composites
+    def apply_filter(self, x, H):
+        """x -> crop(istft(stft(x) * H))   (blind_bwe_utils.apply_filter)."""
+        return self.ola(self.filter_frames(self.stft(x), H), normalise=True)
+
+
+def make_fit_cfg(mu=(1000.0, 10.0), tol=(5e-3, 5e-3), max_iter=100, fcmin=20.0, fcmax=22050.0, Amin=-50.0, Amax=30.0,
+                 clamp_fc=True, clamp_A=True, only_negative_A=True, weighting="sqrt"):
+    c = FitCfg()
+    c.mu_fc, c.mu_A, c.tol_fc, c.tol_A = float(mu[0]), float(mu[1]), float(tol[0]), float(tol[1])
+    c.fcmin, c.fcmax, c.Amin, c.Amax = float(fcmin), float(fcmax), float(Amin), float(Amax)
+    c.max_iter, c.clamp_fc, c.clamp_A, c.only_negative_A = int(max_iter), int(clamp_fc), int(clamp_A), int(only_negative_A)
+    if weighting not in _WEIGHTS:
+        raise NotImplementedError(f"freq_weighting_filter={weighting!r} (implemented: {sorted(_WEIGHTS)})")
+    c.weighting = _WEIGHTS[weighting]
+    return c

@@ -113,6 +113,51 @@ int babe_cqt_gather(const float* bs, long bs_stride, const int* rowptr, const in
 int babe_spec_scale(const float* spec_in, const float* spec2, float* spec_out, const float* mul, int KX, int L,
                     float scale, float scale2, int B, void* stream);
 
+/* ---- STFT-domain degradation model: utils/blind_bwe_utils.py:6-39 (apply_stft / apply_filter_istft /
+ * apply_filter) and testing/blind_bwe_sampler.py:518-595.  nfft in {256..4096} (power of two), hop nfft/2,
+ * periodic Hamming window, NFFT zeros appended, frames = 1 + L/hop.  spec: [B][frames][nfft/2+1] float2. */
+/* spec = rfft(frame * w); if pre (length nfft+hop*(frames-1)) != NULL the signal is multiplied by pre[n] first
+ * (1/envelope, used by the adjoint of the iSTFT normalisation). */
+int babe_stft_fwd(const float* x, long x_bs, int L, const float* pre, float* spec, int B, int nfft, int frames,
+                  const float* tw4096, void* stream);
+/* frames_out[b][t][:] = w * irfft(spec[b][t] * H[b or 0][:]) ; H stride H_bs (0 = one filter for the batch) */
+int babe_spec_filter_istft(const float* spec, const float* H, long H_bs, float* frames_out, int B, int nfft,
+                           int frames, const float* tw4096, void* stream);
+/* overlap-add of frames, times post[n] if given (1/envelope), cropped to L.
+ * y == NULL: out = ola.   y != NULL: out = y - ola (the residual) and part[b][blk] = sum of squares (double). */
+int babe_ola(const float* frames_in, const float* post, const float* y, long y_bs, float* out, long out_bs,
+             double* part, int nblk, int B, int L, int nfft, int frames, void* stream);
+/* out[b][n] = -r[b][n] / ||r_b|| * post[n]  (seed of the guidance VJP: d||y-Ax|| / d(pre-normalisation OLA)).
+ * shared_norm=1 is NOT used for the norm (the reference's norm is per item, blind_bwe_sampler.py:117). */
+int babe_residual_seed(const float* r, long r_bs, const double* part, int nblk, const float* post, float* out,
+                       long out_bs, int B, int L, void* stream);
+/* per-bin sufficient statistics of the magnitude fit: stats[b][0..2][k] (double) =
+ * sum_t |X|^2, sum_t |X||Y|, sum_t |Y|^2.  shared=1 sums over the batch too (reference batch semantics). */
+int babe_stft_mag_stats(const float* specX, const float* specY, double* stats, int B, int nbins, int frames,
+                        int shared, void* stream);
+/* design_filter (utils/blind_bwe_utils.py:82-119): params [P][2][K] (fc row, A row) -> H [P][nbins];
+ * bin frequencies are float32(k) * float32(fs/nfft) and masks are evaluated in float32 like the reference. */
+int babe_design_filter(const float* params, float* H, int P, int K, int nbins, float fs, int nfft, void* stream);
+typedef struct {
+    float mu_fc, mu_A, tol_fc, tol_A, fcmin, fcmax, Amin, Amax;
+    int max_iter, clamp_fc, clamp_A, only_negative_A, weighting; /* 0 None, 1 sqrt, 2 linear, 3 log */
+} babe_fit_cfg;
+/* BlindSampler.fit_params (:533-595): projected gradient descent on (fc, A) from the statistics.
+ * params [P][2][K] updated in place; n_iter[P] receives the iteration count. K <= 8. */
+int babe_filter_fit(const double* stats, float* params, int* n_iter, int P, int K, int nbins, float fs, int nfft,
+                    const babe_fit_cfg* cfg, void* stream);
+
+/* ---- sampler element-wise steps: testing/blind_bwe_sampler.py:503-516, :125-135, :701-761; edm.py:144-159 */
+/* out = a*x + b*y + c*z (y, z optional) over n elements */
+int babe_lincomb3(float* out, float a, const float* x, float b, const float* y, float c, const float* z, long n,
+                  void* stream);
+/* part[b][blk] = sum of squares of g[b][blk-th slice] (double) */
+int babe_sumsq_partial(const float* g, long g_bs, double* part, int nblk, int B, long n, void* stream);
+/* d = -t * ((xden - xhat)/t^2 - s_b * g / t),  s_b = xi / (||g_b|| / sqrt(audio_len) + 1e-6);
+ * shared_norm=1 uses the norm over the whole batch (reference semantics, :125). */
+int babe_score_direction(const float* xden, const float* xhat, const float* g, const double* part, int nblk,
+                         float* d, float t, float xi, float audio_len, int shared_norm, int B, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

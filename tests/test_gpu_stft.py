@@ -1,0 +1,97 @@
+"""HIP STFT / filter / fit kernels vs the oracle and the golden vectors.  Needs a MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bwe_utils as U
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(G, name)).items()}
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("nfft", [1024, 4096])
+def test_stft_and_apply_filter_vs_golden(nfft):
+    from babe_amd.stft import STFTOps
+    g = load("stft_filter.npz")
+    gen = torch.Generator().manual_seed(int(g["stft_seed"]))
+    x = torch.randn(2, 20000, generator=gen) * 0.1
+    st = STFTOps(nfft, 20000, 44100, "cuda")
+    spec = st.stft(x.cuda())                                   # [B,frames,bins,2]
+    assert rel(spec.permute(0, 2, 1, 3), g[f"stft_{nfft}"]) < 5e-6
+    H = st.design_filter(torch.tensor([[3000.0, 5000.0], [-20.0, -40.0]]).cuda())
+    Href = U.design_filter(torch.tensor([3000.0, 5000.0]), torch.tensor([-20.0, -40.0]), U.bin_freqs(nfft, 44100))
+    assert rel(H, Href) < 1e-6
+    assert rel(st.apply_filter(x.cuda(), H), g[f"filt_{nfft}"]) < 1e-5
+    assert rel(st.apply_filter(x.cuda(), torch.ones_like(H)), g[f"ident_{nfft}"]) < 1e-5
+
+
+@pytest.mark.parametrize("fs", [44100, 22050])
+@pytest.mark.parametrize("case", ["k1", "k5", "k4_onbin", "k2_nyq"])
+def test_design_filter_vs_golden(fs, case):
+    from babe_amd.stft import STFTOps
+    g = load("stft_filter.npz")
+    st = STFTOps(4096, 8192, fs, "cuda")
+    p = g[f"df_{fs}_{case}_p"]
+    H = st.design_filter(p.cuda()).cpu()
+    Href = g[f"df_{fs}_{case}_H"]
+    # bit-exact bin indexing: the pass-band / transition masks must coincide exactly
+    assert torch.equal(H == 1.0, Href == 1.0)
+    assert float(((H - Href).abs() / Href).max()) < 3e-6
+
+
+def test_guidance_forward_and_vjp():
+    """norm = ||y - A_H(x)||_2 and its gradient w.r.t. x through STFT -> H -> iSTFT."""
+    from babe_amd.stft import STFTOps
+    L = 30000
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(2, L, generator=gen) * 0.1
+    y = torch.randn(2, L, generator=gen) * 0.1
+    st = STFTOps(4096, L, 44100, "cuda")
+    params = torch.tensor([[1000.0, 3000.0], [-10.0, -30.0]])
+    H = st.design_filter(params.cuda())
+    xr = x.double().requires_grad_(True)
+    Hd = U.design_filter(params[0].double(), params[1].double(), U.bin_freqs(4096, 44100).double())
+    rec = U.apply_filter(xr, Hd, 4096)
+    norm = torch.linalg.norm(y.double() - rec, dim=1)
+    gref, = torch.autograd.grad(norm.sum(), xr)
+    r, part = st.ola(st.filter_frames(st.stft(x.cuda()), H), normalise=True, y=y.cuda())
+    assert rel(part.sum(1).sqrt(), norm) < 1e-5
+    seed = st.residual_seed(r, part)
+    gx = st.ola(st.filter_frames(st.stft(seed), H), normalise=False)
+    assert rel(gx, gref) < 2e-5
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_filter_fit_vs_golden(ci):
+    from babe_amd.stft import STFTOps, make_fit_cfg
+    g = load("fit_params.npz")
+    seed, B, n = int(g[f"fit{ci}_seed"]), int(g[f"fit{ci}_B"]), int(g[f"fit{ci}_n"])
+    fc_true, A_true = [float(v) for v in g[f"fit{ci}_true"]]
+    gen = torch.Generator().manual_seed(seed)
+    xd = torch.randn(B, n, generator=gen) * 0.1
+    f = U.bin_freqs(4096, 44100)
+    y = U.apply_filter(xd, U.design_filter(torch.tensor([fc_true]), torch.tensor([A_true]), f), 4096) \
+        + 1e-3 * torch.randn(B, n, generator=gen)
+    st = STFTOps(4096, n, 44100, "cuda")
+    stats = st.mag_stats(st.stft(xd.cuda()), st.stft(y.cuda()), shared=True)      # reference batch semantics
+    p0 = torch.tensor([[[280.0, 285.0, 290.0, 295.0, 300.0], [-15.0, -17.0, -20.0, -25.0, -30.0]]])
+    for mi in (1, 2, 5):
+        p = p0.clone().cuda()
+        st.filter_fit(stats, p, make_fit_cfg(max_iter=mi, fcmax=22050))
+        assert torch.allclose(p[0].cpu(), g[f"fit{ci}_it{mi}"], rtol=5e-5, atol=5e-4), (mi, p, g[f"fit{ci}_it{mi}"])
+    p = p0.clone().cuda()
+    nit = st.filter_fit(stats, p, make_fit_cfg(fcmax=22050))
+    ref = g[f"fit{ci}_final"]
+    assert torch.allclose(p[0, 0].cpu(), ref[0], rtol=1e-2) and torch.allclose(p[0, 1].cpu(), ref[1], atol=0.5), (p, ref, nit)
