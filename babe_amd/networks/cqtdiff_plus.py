@@ -1,0 +1,172 @@
+"""CQTDiff+ denoiser (HIP-backed), drop-in for the reference's
+``networks.cqtdiff+.Unet_CQT_oct_with_attention`` (/root/reference/networks/cqtdiff+.py:583-845).
+
+Same constructor ``(args, device)``, same ``state_dict`` key names / shapes so the
+reference's checkpoints load with ``load_state_dict(state['ema'])``; ``net(x[B,L], cnoise[B,1]) ->
+[B,L]``; ``net.CQTransform.apply_hpf_DC``.  The forward is autograd-transparent w.r.t. ``x`` (a
+``torch.autograd.Function`` whose backward is the hand-wired HIP input-VJP), so the reference's own
+sampler code - which calls ``torch.autograd.grad`` through the model - runs on it unchanged.
+There is no CPU path: device must be a GPU and libbabe_hip.so must be present.
+
+Not implemented (disabled in every blind-BWE config, conf/network/cqtdiff+.yaml:8,23):
+frequency encodings (``use_fencoding``) and time-attention layers.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..cqt import CQT_nsgt
+from .unet_engine import UnetEngine
+
+
+def param_specs(Ns, num_dils, emb_dim=256, num_octs=7):
+    """[(key, shape, init)] for every parameter/buffer of the reference module, init in {'w','gate','ones','rff','buf'}."""
+    out = [("embedding.RFF_freq", (1, 32), "rff")]
+    for i, (o, k) in enumerate([(128, 64), (256, 128), (emb_dim, 256)]):
+        out += [(f"embedding.MLP.{i}.weight", (o, k), "w"), (f"embedding.MLP.{i}.bias", (o,), "zero")]
+    out += [("downsamplerT.kernel", (8,), "buf"), ("upsamplerT.kernel", (8,), "buf")]
+
+    def block(p, dim, dim_out, nd, k, after):
+        N = dim if after else dim_out
+        r = []
+        if after and N != dim_out:
+            r.append((p + "proj_out.weight", (dim_out, N, 1, 1), "w"))
+        if dim != dim_out:
+            r.append((p + "res_conv.weight", (dim_out, dim, 1, 1), "w"))
+        if dim != N:
+            r.append((p + "proj_in.weight", (N, dim, 1, 1), "w"))
+        for d in range(nd):
+            r += [(p + f"norm.{d}.gamma", (1, N, 1, 1), "ones"),
+                  (p + f"affine.{d}.weight", (N, emb_dim), "w"), (p + f"affine.{d}.bias", (N,), "zero"),
+                  (p + f"gate.{d}.weight", (N, emb_dim), "gate"), (p + f"gate.{d}.bias", (N,), "zero"),
+                  (p + f"H.{d}.weight", (N, N, k[0], k[1]), "w")]
+        return r
+
+    for i in range(num_octs):
+        din, dout = (Ns[0], Ns[0]) if i == 0 else (Ns[i - 1], Ns[i])
+        out += block(f"downs.{i}.0.", 2, din, 1, (1, 1), False)
+        out.append((f"downs.{i}.1.weight", (dout, 2, 5, 3), "w"))
+        out += block(f"downs.{i}.2.", din, dout, num_dils[i], (5, 3), False)
+    out += block("middle.0.0.", Ns[-1], 2, 1, (1, 1), True)
+    out += block("middle.0.1.", Ns[-1], Ns[-1], num_dils[-1], (5, 3), False)
+    for ii, i in enumerate(range(num_octs - 1, -1, -1)):
+        din, dout = (Ns[0] * 2, Ns[0]) if i == 0 else (Ns[i] * 2, Ns[i - 1])
+        out += block(f"ups.{ii}.0.", dout, 2, 1, (1, 1), True)
+        out += block(f"ups.{ii}.1.", din, dout, num_dils[i], (5, 3), False)
+    return out
+
+
+CUBIC = [-0.01171875, -0.03515625, 0.11328125, 0.43359375, 0.43359375, 0.11328125, -0.03515625, -0.01171875]
+
+
+def init_state_dict(Ns, num_dils, emb_dim=256, seed=0, gate_scale=1e-7):
+    """Random weights with the reference's init rule (kaiming_uniform * sqrt(1/3); gates * 1e-7, cqtdiff+.py:599-600).
+    gate_scale=1 gives O(1) gates (an untrained net with 1e-7 gates has numerically dead residual branches)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for key, shape, kind in param_specs(Ns, num_dils, emb_dim):
+        if kind in ("w", "gate"):
+            fan_in = int(np.prod(shape[1:]))
+            w = math.sqrt(3.0 / fan_in) * (torch.rand(shape, generator=g) * 2 - 1)
+            sd[key] = w * (math.sqrt(1 / 3) if kind == "w" else gate_scale)
+        elif kind == "zero":
+            sd[key] = torch.zeros(shape)
+        elif kind == "ones":
+            sd[key] = torch.ones(shape)
+        elif kind == "rff":
+            sd[key] = 16 * torch.randn(shape, generator=g)
+        else:
+            sd[key] = torch.tensor(CUBIC)
+    return sd
+
+
+class _Node(nn.Module):
+    """Anonymous container so that parameter paths reproduce the reference's dotted names."""
+
+
+def _attach(root, key, tensor, is_buffer):
+    parts = key.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    if is_buffer:
+        node.register_buffer(parts[-1], tensor)
+    else:
+        node.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class _UnetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cnoise, net):
+        ctx.net = net
+        return net.fwd_nograd(x, cnoise)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.net.vjp(g.contiguous()), None, None
+
+
+class Unet_CQT_oct_with_attention(nn.Module):
+    def __init__(self, args, device):
+        super().__init__()
+        self.args = args
+        nw = args.network
+        if nw.get("use_fencoding", False):
+            raise NotImplementedError("use_fencoding=True (disabled in the blind-BWE configs)")
+        if any(nw.get("attention_layers", [0])):
+            raise NotImplementedError("attention layers (disabled in the blind-BWE configs)")
+        if not nw.get("use_norm", True):
+            raise NotImplementedError("use_norm=False")
+        self.Ns, self.num_dils = list(nw.Ns), list(nw.num_dils)
+        self.num_octs, self.bins_per_oct = nw.cqt.num_octs, nw.cqt.bins_per_oct
+        assert self.num_octs == 7 and len(self.Ns) == 7
+        self.emb_dim = nw.emb_dim
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("babe_amd networks run on the GPU only (no CPU fallback); use device='cuda'")
+        win = ("kaiser", nw.cqt.beta) if nw.cqt.window == "kaiser" else nw.cqt.window
+        self.CQTransform = CQT_nsgt(self.num_octs, self.bins_per_oct, mode="oct", window=win,
+                                    fs=args.exp.sample_rate, audio_len=args.exp.audio_len, device=self.device)
+        for key, t in init_state_dict(self.Ns, self.num_dils, self.emb_dim).items():
+            _attach(self, key, t.to(self.device), is_buffer=key.endswith(".kernel"))
+        self._engine = None
+        self.register_load_state_dict_post_hook(lambda m, k: setattr(m, "_engine", None))
+
+    # ---------------------------------------------------------------- engine
+    def engine(self):
+        if self._engine is None:
+            sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in self.state_dict().items()}
+            self._engine = UnetEngine(sd, self.Ns, self.num_dils, self.num_octs, self.bins_per_oct)
+        return self._engine
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    # ---------------------------------------------------------------- raw (no autograd) interface
+    def fwd_nograd(self, x, cnoise):
+        """x [B,L], cnoise [B,1] -> [B,L]; keeps what vjp() needs until the next call."""
+        eng = self.engine()
+        x = x.detach().contiguous().float()
+        assert x.shape[-1] == self.CQTransform.Ls, "input length must equal exp.audio_len (the CQT is built for it)"
+        film = eng.embed(cnoise.detach().reshape(-1, 1).contiguous().float())
+        co = self.CQTransform.fwd_planar(x)
+        outs = eng.forward(co, film)
+        return self.CQTransform.bwd_planar(outs)
+
+    def vjp(self, g):
+        """Gradient of <net(x), g> w.r.t. x for the last fwd_nograd call."""
+        eng = self.engine()
+        gouts = self.CQTransform.bwd_adjoint(g.contiguous())
+        gC = eng.vjp(gouts)
+        return self.CQTransform.fwd_adjoint(gC)
+
+    # ---------------------------------------------------------------- nn.Module call
+    def forward(self, inputs, sigma):
+        if torch.is_grad_enabled() and inputs.requires_grad:
+            return _UnetFn.apply(inputs, sigma, self)
+        return self.fwd_nograd(inputs, sigma)

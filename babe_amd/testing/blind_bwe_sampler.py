@@ -1,0 +1,203 @@
+"""Guided stochastic-Heun EDM sampler for (blind) bandwidth extension on the babe_hip kernels.
+
+Drop-in for the reference's ``testing.blind_bwe_sampler.BlindSampler``
+(/root/reference/testing/blind_bwe_sampler.py): same constructor ``(model, diff_params, args,
+rid=False)`` and the same ``predict_blind_bwe`` :619-769 / ``predict_bwe(..., 'fc_A')`` :306-364
+call surface and return values.  Per score evaluation (:685-761):
+
+  x_den  = hpf_DC( c_skip x + c_out F(c_in x, ln(sigma)/4) )            get_denoised_estimate :152-157
+  params = projected GD on the STFT-magnitude fit                      fit_params :533-595
+  g      = d/dx || y - iSTFT(H(params) STFT(x_den)) ||_2  (through F)  get_rec_grads :75-123
+  score  = (x_den - x)/t^2 - xi/(||g||/sqrt(L)+1e-6) g/t               :125-135, :701
+
+No autograd: the guidance gradient is the hand-wired VJP (STFT/iSTFT adjoints, self-adjoint
+high-pass, UNet input-VJP).  All tensor work is C-ABI calls; the host only sequences them.
+
+``batch_semantics``:
+  'reference' - one shared filter for the batch and a whole-batch guidance norm, exactly what the
+                reference does for B>1 (blind_bwe_utils.py:295 flattens B; blind_bwe_sampler.py:125).
+  'per_clip'  - every clip has its own filter and guidance norm (== the reference run at B=1 per
+                clip); this is what independent-clip batching/sharding uses.  Identical at B=1.
+"""
+import torch
+
+from ..stft import STFTOps, lincomb, make_fit_cfg
+from .._lib import check, lib, ptr, stream
+
+
+class BlindSampler:
+    NBLK = 64
+
+    def __init__(self, model, diff_params, args, rid=False, batch_semantics="per_clip", noise_device="cpu"):
+        self.model = model
+        self.diff_params = diff_params
+        self.args = args
+        if not args.tester.diff_params.same_as_training:
+            self.update_diff_params()
+        ps = args.tester.posterior_sampling
+        self.order = args.tester.order
+        self.xi = ps.xi
+        self.data_consistency = ps.data_consistency
+        self.nb_steps = args.tester.T
+        bb = args.tester.blind_bwe
+        self.mu = [bb.optimization.mu[0], bb.optimization.mu[1]]
+        self.fcmin = bb.fcmin
+        self.fcmax = args.exp.sample_rate // 2 if bb.fcmax == "nyquist" else bb.fcmax
+        self.Amin, self.Amax = bb.Amin, bb.Amax
+        self.tol = bb.optimization.tol
+        self.start_sigma = None if ps.start_sigma == "None" else ps.start_sigma
+        if ps.norm != 2 or ps.stft_distance.use:
+            raise NotImplementedError("only posterior_sampling.norm=2 (the default of every blind-BWE config)")
+        if ps.SNR_observations != "None" or bb.get("sigma_den_estimate", 0):
+            raise NotImplementedError("observation-noise regularisation (SNR_observations / sigma_den_estimate)")
+        if self.data_consistency:
+            raise NotImplementedError("data_consistency=True ('always False for blind bwe', conf/tester/blind_bwe.yaml)")
+        assert batch_semantics in ("per_clip", "reference")
+        self.batch_semantics = batch_semantics
+        self.noise_device = noise_device
+        self.fit_cfg = make_fit_cfg(mu=self.mu, tol=self.tol, max_iter=bb.optimization.max_iter, fcmin=self.fcmin,
+                                    fcmax=self.fcmax, Amin=self.Amin, Amax=self.Amax,
+                                    clamp_fc=bb.optimization.clamp_fc, clamp_A=bb.optimization.clamp_A,
+                                    only_negative_A=bb.optimization.only_negative_A,
+                                    weighting=ps.freq_weighting_filter)
+        self._stft = None
+
+    def update_diff_params(self):
+        dp, src = self.diff_params, self.args.tester.diff_params
+        dp.sigma_min, dp.sigma_max, dp.ro, dp.sigma_data = src.sigma_min, src.sigma_max, src.ro, src.sigma_data
+        dp.Schurn, dp.Stmin, dp.Stmax, dp.Snoise = src.Schurn, src.Stmin, src.Stmax, src.Snoise
+
+    # ------------------------------------------------------------------ helpers
+    def stft_ops(self, L, device):
+        if self._stft is None or self._stft.L != L:
+            self._stft = STFTOps(self.args.tester.blind_bwe.NFFT, L, self.args.exp.sample_rate, device)
+        return self._stft
+
+    def _randn(self, shape, device):
+        if self.noise_device == "cpu":
+            return torch.randn(shape).to(device)          # reference: CPU draw then copy (:513, edm.py:105)
+        return torch.randn(shape, device=device)
+
+    def _sumsq(self, g):
+        B, n = g.shape
+        part = torch.empty(B, self.NBLK, device=g.device, dtype=torch.float64)
+        check(lib().babe_sumsq_partial(ptr(g), g.stride(0), ptr(part), self.NBLK, B, n, stream()), "sumsq_partial")
+        return part
+
+    def get_denoised_estimate(self, x, t):
+        """x [B,L] device, t host float -> hpf_DC(denoiser(x))  (:152-157); keeps the UNet context for the VJP."""
+        dp = self.diff_params
+        s = torch.as_tensor(t, dtype=torch.float32)
+        self._c = (float(dp.cskip(s)), float(dp.cout(s)), float(dp.cin(s)))
+        cskip, cout, cin = self._c
+        B = x.shape[0]
+        xin = lincomb(torch.empty_like(x), cin, x)
+        cn = dp.cnoise(s).reshape(1, 1).expand(B, 1).contiguous().to(x.device)
+        net = self.model.fwd_nograd(xin, cn)
+        xd = lincomb(torch.empty_like(x), cskip, x, cout, net)
+        if self.args.tester.filter_out_cqt_DC_Nyq:
+            xd = self.model.CQTransform.apply_hpf_DC(xd)
+        return xd
+
+    def fit_params(self, specX, specY, filter_params):
+        """filter_params [P,2,K] (device) updated by the projected GD (:533-595); returns (params, n_iter)."""
+        st = self._stft
+        stats = st.mag_stats(specX, specY, shared=(self.batch_semantics == "reference"))
+        p = filter_params.clone()
+        nit = st.filter_fit(stats, p, self.fit_cfg)
+        return p, nit
+
+    def evaluate(self, x, t, y, specY, filter_params, blind):
+        """One score evaluation at noise level t. Returns (d = -t*score, x_den, filter_params)."""
+        st = self._stft
+        cq = self.model.CQTransform
+        B, L = x.shape
+        x_den = self.get_denoised_estimate(x, t)
+        cskip, cout, cin = self._c
+        specX = st.stft(x_den)
+        if blind:
+            filter_params, self.last_n_iter = self.fit_params(specX, specY, filter_params)
+        H = st.design_filter(filter_params)                     # [P,nbins]
+        Hq = H if H.shape[0] == B else H[0]
+        # reconstruction guidance: forward residual and hand-wired VJP
+        r, part = st.ola(st.filter_frames(specX, Hq), normalise=True, y=y)
+        seed = st.residual_seed(r, part)
+        g_den = st.ola(st.filter_frames(st.stft(seed), Hq), normalise=False)
+        if self.args.tester.filter_out_cqt_DC_Nyq:
+            g_den = cq.apply_hpf_DC(g_den)                      # zero-phase real filter: self-adjoint
+        g_net = lincomb(torch.empty_like(g_den), cout, g_den)
+        g_xin = self.model.vjp(g_net)
+        g_x = lincomb(torch.empty_like(g_den), cskip, g_den, cin, g_xin)
+        gpart = self._sumsq(g_x)
+        d = torch.empty_like(x)
+        check(lib().babe_score_direction(ptr(x_den), ptr(x), ptr(g_x), ptr(gpart), self.NBLK, ptr(d), float(t),
+                                         float(self.xi), float(self.args.exp.audio_len),
+                                         int(self.batch_semantics == "reference"), B, L, stream()), "score_direction")
+        return d, x_den, filter_params
+
+    # ------------------------------------------------------------------ sampling loops
+    def _sample(self, y, filter_params, blind, rid):
+        dp = self.diff_params
+        device = y.device
+        y = y.contiguous().float()
+        B, L = y.shape
+        st = self.stft_ops(L, device)
+        specY = st.stft(y)
+        T = self.nb_steps
+        if rid:
+            data_denoised = torch.zeros((T, B, L))
+            data_filters = torch.zeros((T, *filter_params.shape[-2:])) if filter_params.shape[0] == 1 else \
+                torch.zeros((T, *filter_params.shape))
+        if self.start_sigma is None:
+            t = dp.create_schedule(T)
+            x = self._randn((B, L), device) * float(t[0])
+        else:
+            t = dp.create_schedule_from_initial_t(self.start_sigma, T)
+            x = lincomb(torch.empty_like(y), 1.0, y, float(t[0]), self._randn((B, L), device).contiguous())
+        gamma = dp.get_gamma(t)
+        for i in range(T):
+            # move_timestep (:509-516), Snoise = 1 as in predict_blind_bwe (:687)
+            t_hat = t[i] + gamma[i] * t[i]
+            eps = self._randn((B, L), device).contiguous()
+            x_hat = lincomb(torch.empty_like(x), 1.0, x, float((t_hat ** 2 - t[i] ** 2) ** (1 / 2)), eps)
+            d, x_den, filter_params = self.evaluate(x_hat, float(t_hat), y, specY, filter_params, blind)
+            if rid:
+                data_denoised[i] = x_den.cpu()
+                data_filters[i] = (filter_params[0] if filter_params.shape[0] == 1 else filter_params).cpu()
+            h = float(t[i + 1] - t_hat)
+            if float(t[i + 1]) != 0 and self.order == 2:
+                x_prime = lincomb(torch.empty_like(x), 1.0, x_hat, h, d)
+                d2, _, filter_params = self.evaluate(x_prime, float(t[i + 1]), y, specY, filter_params, blind)
+                x = lincomb(torch.empty_like(x), 1.0, x_hat, 0.5 * h, d, 0.5 * h, d2)
+            else:
+                x = lincomb(torch.empty_like(x), 1.0, x_hat, h, d)
+        fp_out = filter_params[0] if (filter_params.shape[0] == 1) else filter_params
+        if rid:
+            return x, fp_out, data_denoised, t, data_filters
+        return x, fp_out
+
+    def _init_params(self, B, device):
+        ic = self.args.tester.blind_bwe.initial_conditions
+        p = torch.tensor([list(ic.fc), list(ic.A)], dtype=torch.float32)
+        if p.dim() == 1:
+            p = p.unsqueeze(1)
+        P = 1 if self.batch_semantics == "reference" else B
+        return p.unsqueeze(0).repeat(P, 1, 1).contiguous().to(device)
+
+    def predict_blind_bwe(self, y, rid=False, compute_sweep=False):
+        """y [B,L] observations on the GPU -> (x, filter_params[, data_denoised, t, data_filters])."""
+        if compute_sweep:
+            raise NotImplementedError("compute_sweep (logging only)")
+        return self._sample(y, self._init_params(y.shape[0], y.device), blind=True, rid=rid)
+
+    def predict_bwe(self, ylpf, filt, filt_type, rid=False, test_filter_fit=False, compute_sweep=False):
+        """Known-degradation variant (:306-364). Implemented: filt_type='fc_A' (filt = [2,K] tensor)."""
+        if filt_type != "fc_A":
+            raise NotImplementedError(f"filt_type={filt_type!r}: only 'fc_A' runs on the HIP path")
+        if test_filter_fit or compute_sweep:
+            raise NotImplementedError("test_filter_fit / compute_sweep (logging only)")
+        p = torch.as_tensor(filt, dtype=torch.float32)
+        if p.dim() == 1:
+            p = p.unsqueeze(1)
+        res = self._sample(ylpf, p.unsqueeze(0).contiguous().to(ylpf.device), blind=False, rid=rid)
+        return res if rid else res[0]
