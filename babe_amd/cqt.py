@@ -158,6 +158,22 @@ class RealFFT:
 
     def rfft(self, x, out=None):
         """x [B,L] -> planar spectrum [B,2,KX] (bins above L/2 hold valid but redundant values)."""
+        lib().babe_conv_prof_pause(1)
+        try:
+            return self._rfft(x, out)
+        finally:
+            lib().babe_conv_prof_pause(0)
+
+    def rfft_T(self, spec, out=None):
+        """Transpose (real-linear adjoint) of rfft: planar [B,2,KX] (entries above L/2 must be 0) -> [B,L].
+        irfft(X) = rfft_T(c*X/L) with c = 1 at DC/Nyquist and 2 elsewhere."""
+        lib().babe_conv_prof_pause(1)
+        try:
+            return self._rfft_T(spec, out)
+        finally:
+            lib().babe_conv_prof_pause(0)
+
+    def _rfft(self, x, out=None):
         B = x.shape[0]
         N1, N2, K2 = self.N1, self.N2, self.K2
         A = torch.empty(B, 2 * N1, 1, N2, device=self.dev)
@@ -169,9 +185,7 @@ class RealFFT:
         ops.conv2d(At, self.W3, out.view(B, 2 * K2, 1, N1))
         return out
 
-    def rfft_T(self, spec, out=None):
-        """Transpose (real-linear adjoint) of rfft: planar [B,2,KX] (entries above L/2 must be 0) -> [B,L].
-        irfft(X) = rfft_T(c*X/L) with c = 1 at DC/Nyquist and 2 elsewhere."""
+    def _rfft_T(self, spec, out=None):
         B = spec.shape[0]
         N1, N2, K2 = self.N1, self.N2, self.K2
         At = torch.empty(B, 2 * N2, 1, N1, device=self.dev)

@@ -210,6 +210,58 @@ int launch_conv(const babe_conv_args& a, ConvGeom g, hipStream_t s) {
 
 }  // namespace
 
+// ---- optional per-launch timing of the conv kernel (bench.py roofline): HIP events on the launch stream
+#include <vector>
+namespace {
+struct ConvProf {
+    bool on = false;
+    bool paused = false;
+    std::vector<hipEvent_t> ev;      // pairs (start, stop)
+    size_t used = 0;
+    double flops = 0;
+} g_prof;
+}  // namespace
+
+extern "C" int babe_conv_prof_enable(int on) {
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    g_prof.flops = 0;
+    return BABE_OK;
+}
+
+extern "C" int babe_conv_prof_pause(int paused) {
+    g_prof.paused = paused != 0;
+    return BABE_OK;
+}
+
+extern "C" int babe_conv_prof_read(double* ms_total, double* flops_total, long* launches) {
+    double ms = 0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) {
+            babe_set_error("conv_prof_read: hipEventSynchronize failed");
+            return BABE_ERR_HIP;
+        }
+        float t = 0;
+        hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
+        ms += t;
+    }
+    if (ms_total) *ms_total = ms;
+    if (flops_total) *flops_total = g_prof.flops;
+    if (launches) *launches = (long)(g_prof.used / 2);
+    g_prof.used = 0;
+    g_prof.flops = 0;
+    return BABE_OK;
+}
+
+static hipEvent_t prof_event() {
+    if (g_prof.used == g_prof.ev.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        g_prof.ev.push_back(e);
+    }
+    return g_prof.ev[g_prof.used++];
+}
+
 extern "C" long babe_conv_packed_size(int Cout, int Cin, int KH, int KW, int transpose_flip) {
     const int co = transpose_flip ? Cin : Cout;
     const int ci = transpose_flip ? Cout : Cin;
@@ -249,6 +301,16 @@ extern "C" int babe_conv2d(const babe_conv_args* ap, void* stream) {
     const long blocks256 = ((npos + 255) / 256) * (n32 / NT) * a.B;
     const bool wp2 = blocks256 >= 512;
     hipStream_t s = (hipStream_t)stream;
+    const bool prof = g_prof.on && !g_prof.paused;
+    if (prof) {
+        hipEventRecord(prof_event(), s);
+        g_prof.flops += 2.0 * a.B * (double)a.Cout * a.Cin * a.KH * a.KW * (double)a.F * a.T;
+    }
+    struct ProfStop {
+        hipStream_t s;
+        bool on;
+        ~ProfStop() { if (on) hipEventRecord(prof_event(), s); }
+    } prof_stop{s, prof};
     if (wp2) {
         switch (NT) {
             case 4: launch_conv<4, 2>(a, g, s); break;

@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the blind-BWE guided reverse-diffusion hot path on MI355X.
+
+Metric (BASELINE.json): audio-seconds restored per wall-second, 10 s @ 44.1 kHz clips, 35 EDM
+steps (2nd order, 69 score evaluations), blind low-pass estimation; whole-job aggregate over
+all ranks.  One "step" = ONE 10 s clip per GPU through BlindSampler.predict_blind_bwe: the clip is
+cut into two 368368-sample segments (the reference's model length, conf/exp/maestro44k_8s.yaml:52;
+segmentation as formal_test_bwe, testing/blind_bwe_tester.py:421-469) that run as one batch of 2
+with per-clip semantics.  Weak scaling: every rank restores its own clips; one RCCL all_gather of
+the restored audio + filters closes each step.
+
+Usage:  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FS = 44100
+SEG = 368368            # exp.audio_len of the 44.1 kHz model
+CLIP_SEC = 10.0
+CLIP = int(CLIP_SEC * FS)
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def synth_clip(clip_id, n=CLIP, fs=FS):
+    """Piano-like synthetic clip: decaying harmonic partials on a random note sequence."""
+    g = torch.Generator().manual_seed(1000 + clip_id)
+    t = torch.arange(n, dtype=torch.float64) / fs
+    x = torch.zeros(n, dtype=torch.float64)
+    onset = 0.0
+    while onset < n / fs:
+        midi = int(torch.randint(40, 88, (1,), generator=g))
+        f0 = 440.0 * 2 ** ((midi - 69) / 12)
+        dur = 0.25 + 1.5 * float(torch.rand(1, generator=g))
+        npart = int(torch.randint(8, 17, (1,), generator=g))
+        tt = (t - onset).clamp(min=0)
+        gate = (t >= onset).double()
+        for k in range(1, npart + 1):
+            fk = f0 * k * math.sqrt(1 + 4e-4 * k * k)
+            if fk > fs / 2 * 0.98:
+                break
+            x += gate * (1.0 / k) * torch.exp(-tt * (1.5 + 0.6 * k)) * torch.sin(2 * math.pi * fk * tt)
+        onset += dur * 0.5
+    x = x + 1e-3 * torch.randn(n, generator=g, dtype=torch.float64)
+    return x.float()
+
+
+def segment_clip(y):
+    """[CLIP] -> [2, SEG]: hop = SEG - 200 - 256 as in formal_test_bwe; the tail is zero-padded."""
+    hop = SEG - 200 - 256
+    segs = torch.zeros(2, SEG, device=y.device)
+    segs[0] = y[:SEG]
+    rest = y[hop:]
+    segs[1, : rest.numel()] = rest
+    return segs, hop
+
+
+def overlap_add(segs, hop, n=CLIP, ola=256):
+    """Hann cross-fade of `ola` samples between consecutive segments (blind_bwe_tester.py:455-499)."""
+    out = torch.zeros(hop + SEG, device=segs.device)
+    w = torch.hann_window(2 * ola, device=segs.device)
+    s0 = segs[0].clone()
+    s0[hop + ola:] = 0
+    s0[hop: hop + ola] *= w[ola:]
+    s1 = segs[1].clone()
+    s1[:ola] *= w[:ola]
+    out[:SEG] += s0
+    out[hop:] += s1
+    return out[:n]
+
+
+def cpu_baseline(threads):
+    """Oracle (CPU restatement of the reference) timed on one score evaluation of a quarter-length segment
+    of the same workload: fs=44100, L=92092, full-width network. Cost per audio-second is identical to the
+    L=368368 segment (work is proportional to the number of CQT frames, i.e. to L)."""
+    from oracle import edm as E
+    from oracle import unet as UN
+    from oracle.nsgt import CQT_nsgt as OracleCQT
+    from oracle.sampler import OracleBlindSampler
+    from babe_amd.networks.cqtdiff_plus import init_state_dict
+    torch.set_num_threads(threads)
+    L = 92092
+    Ns, nd = [64, 96, 96, 128, 128, 256, 256], [2, 3, 4, 5, 6, 7, 7]
+    sd = init_state_dict(Ns, nd, seed=0, gate_scale=1.0)
+    cqt = OracleCQT(7, 64, "oct", ("kaiser", 1), FS, L)
+    cfg = dict(num_octs=7, bins_per_oct=64, num_dils=nd)
+    net = lambda x, cn: UN.unet_forward(sd, cfg, cqt, x, cn)
+    smp = OracleBlindSampler(net, cqt, E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10), fs=FS, audio_len=L, T=35)
+    g = torch.Generator().manual_seed(0)
+    y = 0.1 * torch.randn(1, L, generator=g)
+    x = y + 0.2 * torch.randn(1, L, generator=g)
+    params = torch.tensor([list(smp.fc_init), list(smp.A_init)], dtype=torch.float32)
+    t0 = time.time()
+    smp.evaluate(x, torch.tensor(0.2), y, params, blind=True)
+    dt = time.time() - t0
+    evals_per_segment = 69
+    value = (L / FS) / (evals_per_segment * dt)
+    return {"value": value, "unit": "audio-sec/s", "cores": threads, "kind": "port",
+            "sample": f"1 of 69 score evaluations (UNet fwd+input-VJP, filter fit, guidance) of a {L}-sample "
+                      f"segment at 44.1 kHz (quarter of the 368368-sample segment, same cost per audio-second), "
+                      f"full-width network, {dt:.1f} s on {threads} threads, extrapolated x69"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--T", type=int, default=35, help="EDM steps (35 = the benchmark; anything else is a debug run)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-convs", type=int, default=1)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from babe_amd._lib import lib
+    from babe_amd.config import default_args
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.dist import gather_results
+    from babe_amd.networks.cqtdiff_plus import Unet_CQT_oct_with_attention, init_state_dict
+    from babe_amd.stft import STFTOps
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+
+    args = default_args(sample_rate=FS, audio_len=SEG, T=a.T)
+    net = Unet_CQT_oct_with_attention(args, dev)
+    net.load_state_dict(init_state_dict(args.network.Ns, args.network.num_dils, seed=0, gate_scale=1.0))
+    sampler = BlindSampler(net, EDM(args), args, batch_semantics="per_clip", noise_device="cuda")
+    st = STFTOps(4096, SEG, FS, dev)
+    Hlp = st.design_filter(torch.tensor([[10000.0], [-60.0]], device=dev))
+
+    def make_inputs(step):
+        clip_id = step * world + rank
+        x = synth_clip(clip_id).to(dev)
+        x = x * (0.1 / x.std())
+        segs, hop = segment_clip(x)
+        y = st.apply_filter(segs, Hlp)                       # "22.05 kHz content": nothing above ~11 kHz
+        return y, hop
+
+    torch.manual_seed(2000 + rank)
+    torch.cuda.manual_seed(2000 + rank)
+    nsteps = a.warmup + a.steps
+    inputs = [make_inputs(s) for s in range(nsteps)]          # resident in HBM before the timed region
+
+    def one_step(s):
+        y, hop = inputs[s]
+        x, fp = sampler.predict_blind_bwe(y)
+        clip = overlap_add(x, hop)
+        return gather_results(clip.unsqueeze(0), fp.reshape(1, -1)) if world > 1 else (clip, fp)
+
+    for s in range(a.warmup):
+        one_step(s)
+    L_ = lib()
+    L_.babe_conv_prof_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if a.profile_convs:
+        L_.babe_conv_prof_enable(1)
+    t0 = time.perf_counter()
+    for s in range(a.warmup, nsteps):
+        out = one_step(s)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, fl, nl = C.c_double(0), C.c_double(0), C.c_long(0)
+    if a.profile_convs:
+        L_.babe_conv_prof_read(C.byref(ms), C.byref(fl), C.byref(nl))
+        L_.babe_conv_prof_enable(0)
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    finite = bool(torch.isfinite(out[0]).all())
+
+    if rank == 0:
+        value = world * a.steps * CLIP_SEC / dt
+        roof = None
+        if a.profile_convs and ms.value > 0:
+            ach = fl.value / (ms.value * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM dilated conv, fwd + input-VJP)",
+                    "launches": nl.value, "avg_launch_us": round(ms.value * 1e3 / max(nl.value, 1), 2),
+                    "algorithmic_tflop_per_launch_avg": round(fl.value / max(nl.value, 1) / 1e12, 5),
+                    "kernel_time_share_of_step": round(ms.value * 1e-3 / dt, 4)}
+        rec = {
+            "metric": "audio-sec/s (blind BWE, 10 s @ 44.1 kHz clips, 35 EDM steps 2nd order), whole job",
+            "value": round(value, 5), "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: one 10 s 44.1 kHz clip per GPU per step = 2 segments x 368368 samples, "
+                                   "blind LPF estimation, T=%d EDM steps (order 2, %d score evaluations), fp32, "
+                                   "CQTDiff+ Ns=[64,96,96,128,128,256,256], random-init weights" % (a.T, 2 * a.T - 1),
+                       "segments_per_clip": 2, "segment_len": SEG, "sample_rate": FS, "T": a.T,
+                       "parallelism": "clips sharded over %d GPU(s), RCCL all_gather at end of step" % world,
+                       "headline": a.T == 35},
+            "per_gpu_realtime_factor": round(value / world, 5),
+            "output_finite": finite,
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,12 @@ int babe_conv2d(const babe_conv_args* a, void* stream);
 int babe_conv_pack_weights(const float* w, float* dst, int Cout, int Cin, int KH, int KW,
                            int transpose_flip, void* stream);
 long babe_conv_packed_size(int Cout, int Cin, int KH, int KW, int transpose_flip);
+/* Measurement hook (bench.py): when enabled every babe_conv2d launch is bracketed by HIP events on its
+ * stream; read returns the summed kernel time, the summed ALGORITHMIC flops (2*B*Cout*Cin*KH*KW*F*T with the
+ * unpadded channel counts) and the launch count, then resets. */
+int babe_conv_prof_enable(int on);
+int babe_conv_prof_pause(int paused);   /* exclude launches (the DFT stages of the CQT) from the tally */
+int babe_conv_prof_read(double* ms_total, double* flops_total, long* launches);
 
 /* ---- BiasFreeGroupNorm + FiLM + GELU: cqtdiff+.py:147-163, :472-482 ------------------------ */
 /* partial sums (double) of x and x^2 per (b,group,split): part[(b*G+g)*S+s] = {sum, sumsq} */

@@ -1,0 +1,57 @@
+"""world_size-2 gloo test of the clip sharding + end-of-batch gather (the N>1 path of bench.py)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_clips, q):
+    from babe_amd.dist import gather_results, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(n_clips, rank, world)
+    x = torch.stack([torch.full((16,), float(c)) for c in range(lo, hi)]) if hi > lo else torch.zeros(0, 16)
+    fp = torch.stack([torch.arange(10.0) + 100 * c for c in range(lo, hi)]) if hi > lo else torch.zeros(0, 10)
+    xa, fa = gather_results(x, fp)
+    q.put((rank, xa[:, 0].tolist(), fa[:, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from babe_amd.dist import shard_range
+    for n in (0, 1, 5, 8, 513):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gather_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n_clips = 5
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, xs, fs in res:
+        assert xs == [float(c) for c in range(n_clips)]
+        assert fs == [100.0 * c for c in range(n_clips)]
