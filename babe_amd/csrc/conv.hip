@@ -16,6 +16,7 @@
 #include "../../include/babe_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -23,16 +24,43 @@ struct ConvGeom {
     int CinP, CoutP, pt_log2, pr_log2, tiles_t;
 };
 
-template <int NT, int WP, int KC>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(babe_conv_args a, ConvGeom g) {
+template <int N> struct AVec;
+template <> struct AVec<1> { static __device__ __forceinline__ void ld(const float* p, float* v) { v[0] = p[0]; } };
+template <> struct AVec<2> {
+    static __device__ __forceinline__ void ld(const float* p, float* v) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+};
+template <> struct AVec<3> {
+    static __device__ __forceinline__ void ld(const float* p, float* v) { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; }
+};
+template <> struct AVec<4> {
+    static __device__ __forceinline__ void ld(const float* p, float* v) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+
+// Packed weights are permuted inside every BN-wide output-channel tile so that the NT values one lane feeds to
+// its NT MFMAs are contiguous in LDS: channel co0 + nt*32 + l  is stored at  co0 + l*NT + nt.
+template <int NT, int WP, int KC, int KW>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(babe_conv_args a, ConvGeom g) {
     constexpr int BN = NT * 32;
+    constexpr int NPOS = 128 * WP;          // output positions per block
+    constexpr int TG = 256 / NPOS;          // thread groups that split the KC staged channels
+    constexpr int CPT = KC / TG;            // staged channels per thread
+    constexpr int V4 = BN / 4;
+    constexpr int NWV = KW * KC * V4;       // float4s of weights per chunk
+    constexpr int WJ = (NWV + 255) / 256;
+    constexpr int NSTEP = KW * (KC / 2);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int PT = 1 << g.pt_log2;
     const int PR = 1 << g.pr_log2;
     const int XROW = PT + 2;
-    const int XCH = PR * XROW;
-    float* Xs = smem;
-    float* Ws = smem + ((KC * XCH + 3) & ~3);
+    const int XCH = PR * XROW;              // staged elements per channel (NPOS + 2*PR)
+    const int XBUF = (KC * XCH + 3) & ~3;
+    const int BUF = XBUF + KW * KC * BN;    // floats per LDS buffer (double buffered)
 
     const int tile_t = blockIdx.x % g.tiles_t;
     const int tile_f = blockIdx.x / g.tiles_t;
@@ -60,79 +88,131 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(babe_conv_args a, ConvGe
         const int p = (wave * WP + wp) * 32 + l31;
         boff[wp] = (p >> g.pt_log2) * XROW + (p & (PT - 1)) + h * XCH;
     }
-    const int aoff = h * BN + l31;
+    const int aoff = XBUF + h * BN + l31 * NT;
 
-    const int padt = a.KW >> 1;
+    constexpr int padt = KW >> 1;
     const int khc = a.KH >> 1;
-    // staging geometry: lpr lanes per activation row
-    const int lpr_log2 = g.pt_log2 < 6 ? g.pt_log2 : 6;
-    const int lpr = 1 << lpr_log2;
-    const int rows_per_iter = 256 >> lpr_log2;
-    const int nrows = KC << g.pr_log2;
-    const int srow0 = tid >> lpr_log2;
-    const int scol = tid & (lpr - 1);
     const int cin_split = a.in2 ? a.cin_split : a.Cin;
 
-    for (int kh = 0; kh < a.KH; ++kh) {
+    // ---- per-thread staging slots: two halo-extended positions x CPT channels
+    const int pg = tid & (NPOS - 1);
+    const int cgrp = (TG == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid / NPOS) * CPT;   // wave-uniform
+    int se[2], sr[2], srt[2];
+    bool sv[2], stv[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int e = pg + s2 * NPOS;
+        se[s2] = e;
+        sv[s2] = e < XCH;
+        const int r = e / XROW;
+        const int tt = e - r * XROW;
+        const int t = t0 + tt - padt;
+        sr[s2] = r;
+        stv[s2] = sv[s2] && t >= 0 && t < a.T;
+        srt[s2] = r * a.T + t;
+    }
+    float xr[2][CPT];
+    f32x4 wr[WJ];          // native vector type: stays in registers (HIP's float4 struct array went to scratch)
+    float scj[CPT];        // per-channel input scale of the chunk in flight (wave-uniform)
+    bool cok[CPT];         // channel < Cin
+    bool okm[2];           // position inside the tensor
+
+    auto kh_valid = [&](int kh) {
         const int foff = (kh - khc) * a.dil;
-        // skip taps that fall entirely outside the frequency range for this tile
-        if (f0 + foff + PR <= 0 || f0 + foff >= a.F) continue;
-        for (int ci0 = 0; ci0 < g.CinP; ci0 += KC) {
-            __syncthreads();
-            // ---- stage activations
-            for (int row = srow0; row < nrows; row += rows_per_iter) {
-                const int ci = ci0 + (row >> g.pr_log2);
-                const int r = row & (PR - 1);
-                const int f = f0 + r + foff;
-                const bool rowok = (ci < a.Cin) && (f >= 0) && (f < a.F);
-                const float* src = nullptr;
-                float sc = 1.f;
-                if (rowok) {
-                    src = (ci < cin_split) ? a.in + (long)b * a.in_bs + (long)ci * a.in_cs
-                                           : a.in2 + (long)b * a.in2_bs + (long)(ci - cin_split) * a.in2_cs;
-                    src += (long)f * a.T;
-                    if (a.in_scale) sc = a.in_scale[b * a.Cin + ci];
-                }
-                float* dst = Xs + row * XROW;
-                for (int tt = scol; tt < XROW; tt += lpr) {
-                    const int t = t0 + tt - padt;
-                    float v = 0.f;
-                    if (rowok && t >= 0 && t < a.T) v = src[t] * sc;
-                    dst[tt] = v;
-                }
-            }
-            // ---- stage weights: KW*KC rows of BN contiguous floats
-            {
-                constexpr int V4 = BN / 4;
-                const int nv = a.KW * KC * V4;
-                for (int idx = tid; idx < nv; idx += 256) {
-                    const int row = idx / V4;           // kw*KC + ci_l
-                    const int c4 = idx - row * V4;
-                    const int kw = row / KC;
-                    const int ci_l = row - kw * KC;
-                    const float4 v = *reinterpret_cast<const float4*>(
-                        a.w_packed + ((long)((kh * a.KW + kw) * g.CinP + ci0 + ci_l)) * g.CoutP + co0 + c4 * 4);
-                    *reinterpret_cast<float4*>(Ws + row * BN + c4 * 4) = v;
-                }
-            }
-            __syncthreads();
-            // ---- MFMA
-            for (int kw = 0; kw < a.KW; ++kw) {
+        return !(f0 + foff + PR <= 0 || f0 + foff >= a.F);
+    };
+    auto load_chunk = [&](int kh, int ci0) {
+        const int foff = (kh - khc) * a.dil;
+        // wave-uniform per-channel base pointers and scales (scalar registers / scalar loads)
+        const float* srcj[CPT];
 #pragma unroll
-                for (int q = 0; q < KC / 2; ++q) {
-                    float av[NT], bv[WP];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) av[nt] = Ws[(kw * KC + 2 * q) * BN + aoff + nt * 32];
-#pragma unroll
-                    for (int wp = 0; wp < WP; ++wp) bv[wp] = Xs[2 * q * XCH + boff[wp] + kw];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int wp = 0; wp < WP; ++wp)
-                            acc[nt][wp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nt], bv[wp], acc[nt][wp], 0, 0, 0);
-                }
-            }
+        for (int j = 0; j < CPT; ++j) {
+            const int cir = ci0 + cgrp + j;
+            cok[j] = cir < a.Cin;
+            const int ci = cok[j] ? cir : a.Cin - 1;          // padded channels read a valid address
+            srcj[j] = (ci < cin_split) ? a.in + (long)b * a.in_bs + (long)ci * a.in_cs
+                                       : a.in2 + (long)b * a.in2_bs + (long)(ci - cin_split) * a.in2_cs;
+            scj[j] = a.in_scale ? a.in_scale[b * a.Cin + ci] : 1.f;
         }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int f = f0 + sr[s2] + foff;
+            const bool ok = stv[s2] && f >= 0 && f < a.F;
+            okm[s2] = ok;
+            const long off = ok ? (long)(f0 + foff) * a.T + srt[s2] : 0;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) xr[s2][j] = srcj[j][off];      // raw; masked + scaled at store time
+        }
+#pragma unroll
+        for (int jj = 0; jj < WJ; ++jj) {
+            int idx = tid + jj * 256;
+            if (idx > NWV - 1) idx = NWV - 1;
+            const int row = idx / V4;               // kw*KC + ci_l
+            const int c4 = idx - row * V4;
+            const int kw = row / KC;
+            const int ci_l = row - kw * KC;
+            wr[jj] = *reinterpret_cast<const f32x4*>(
+                a.w_packed + ((long)((kh * KW + kw) * g.CinP + ci0 + ci_l)) * g.CoutP + co0 + c4 * 4);
+        }
+    };
+    auto store_chunk = [&](float* buf) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+            if (sv[s2]) {
+#pragma unroll
+                for (int j = 0; j < CPT; ++j)
+                    buf[(cgrp + j) * XCH + se[s2]] = (okm[s2] && cok[j]) ? xr[s2][j] * scj[j] : 0.f;
+            }
+#pragma unroll
+        for (int jj = 0; jj < WJ; ++jj) {
+            const int idx = tid + jj * 256;
+            if (idx < NWV) *reinterpret_cast<f32x4*>(buf + XBUF + idx * 4) = wr[jj];
+        }
+    };
+
+    int kh = 0;
+    while (!kh_valid(kh)) ++kh;                 // kh = KH/2 is always valid
+    int ci0 = 0;
+    load_chunk(kh, ci0);
+    store_chunk(smem);
+    __syncthreads();
+    int cur = 0;
+    while (true) {
+        int nkh = kh, nci = ci0 + KC;
+        if (nci >= g.CinP) {
+            nci = 0;
+            ++nkh;
+            while (nkh < a.KH && !kh_valid(nkh)) ++nkh;
+        }
+        const bool has_next = nkh < a.KH;
+        if (has_next) load_chunk(nkh, nci);      // global loads stay in flight under the MFMAs below
+        const float* Xs = smem + cur * BUF;
+        // operand registers are prefetched one k-pair ahead of the MFMAs that consume them
+        float av[2][NT], bv[2][WP];
+        AVec<NT>::ld(Xs + aoff, av[0]);
+#pragma unroll
+        for (int wp = 0; wp < WP; ++wp) bv[0][wp] = Xs[boff[wp]];
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            const int c = st & 1;
+            if (st + 1 < NSTEP) {
+                const int kw = (st + 1) / (KC / 2), q = (st + 1) % (KC / 2);
+                AVec<NT>::ld(Xs + aoff + (kw * KC + 2 * q) * BN, av[c ^ 1]);
+#pragma unroll
+                for (int wp = 0; wp < WP; ++wp) bv[c ^ 1][wp] = Xs[2 * q * XCH + boff[wp] + kw];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int wp = 0; wp < WP; ++wp)
+                    acc[nt][wp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][nt], bv[c][wp], acc[nt][wp], 0, 0, 0);
+        }
+        if (has_next) store_chunk(smem + (cur ^ 1) * BUF);
+        __syncthreads();
+        if (!has_next) break;
+        kh = nkh;
+        ci0 = nci;
+        cur ^= 1;
     }
 
     // ---- epilogue
@@ -159,11 +239,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(babe_conv_args a, ConvGe
     }
 }
 
+inline int pick_nt(int CoutP) {
+    const int n32 = CoutP / 32;
+    for (int c = 4; c >= 1; --c)
+        if (n32 % c == 0) return c;
+    return 1;
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int KH,
-                                    int KW, int tf, int CinP, int CoutP, long total) {
+                                    int KW, int tf, int CinP, int CoutP, long total, int NT) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int co = (int)(i % CoutP);
+    // stored position -> logical output channel (inverse of the in-tile permutation co0 + l*NT + nt)
+    const int cs = (int)(i % CoutP);
+    const int BN = NT * 32;
+    const int loc = cs % BN;
+    const int co = cs - loc + (loc % NT) * 32 + loc / NT;
     long r = i / CoutP;
     const int ci = (int)(r % CinP);
     r /= CinP;
@@ -190,7 +281,7 @@ inline int ilog2_ceil(int v) {
     return l;
 }
 
-template <int NT, int WP>
+template <int NT, int WP, int KW>
 int launch_conv(const babe_conv_args& a, ConvGeom g, hipStream_t s) {
     constexpr int KC = 8;
     constexpr int NPOS = 128 * WP;
@@ -203,8 +294,8 @@ int launch_conv(const babe_conv_args& a, ConvGeom g, hipStream_t s) {
     g.tiles_t = cdiv(a.T, PT);
     const int tiles_f = cdiv(a.F, PR);
     dim3 grid(g.tiles_t * tiles_f, g.CoutP / (NT * 32), a.B);
-    const size_t lds = ((size_t)((KC * PR * (PT + 2) + 3) & ~3) + (size_t)3 * KC * NT * 32) * sizeof(float);
-    hipLaunchKernelGGL((conv_mfma_kernel<NT, WP, KC>), grid, dim3(256), lds, s, a, g);
+    const size_t lds = 2 * ((size_t)((KC * PR * (PT + 2) + 3) & ~3) + (size_t)KW * KC * NT * 32) * sizeof(float);
+    hipLaunchKernelGGL((conv_mfma_kernel<NT, WP, KC, KW>), grid, dim3(256), lds, s, a, g);
     return 0;
 }
 
@@ -276,7 +367,7 @@ extern "C" int babe_conv_pack_weights(const float* w, float* dst, int Cout, int 
     const int CinP = (ci + 7) / 8 * 8, CoutP = (co + 31) / 32 * 32;
     const long total = (long)KH * KW * CinP * CoutP;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout,
-                       Cin, KH, KW, transpose_flip, CinP, CoutP, total);
+                       Cin, KH, KW, transpose_flip, CinP, CoutP, total, pick_nt(CoutP));
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }
@@ -293,9 +384,7 @@ extern "C" int babe_conv2d(const babe_conv_args* ap, void* stream) {
     g.CinP = (a.Cin + 7) / 8 * 8;
     g.CoutP = (a.Cout + 31) / 32 * 32;
     const int n32 = g.CoutP / 32;
-    int NT = 1;
-    for (int c = 4; c >= 1; --c)
-        if (n32 % c == 0) { NT = c; break; }
+    const int NT = pick_nt(g.CoutP);
     // positions per block: 256 (WP=2) unless that leaves the chip under-filled
     const long npos = (long)a.F * a.T;
     const long blocks256 = ((npos + 255) / 256) * (n32 / NT) * a.B;
@@ -311,21 +400,25 @@ extern "C" int babe_conv2d(const babe_conv_args* ap, void* stream) {
         bool on;
         ~ProfStop() { if (on) hipEventRecord(prof_event(), s); }
     } prof_stop{s, prof};
+#define BABE_CONV_CASE(NTv, WPv)                                          \
+    if (a.KW == 3) launch_conv<NTv, WPv, 3>(a, g, s);                     \
+    else launch_conv<NTv, WPv, 1>(a, g, s);
     if (wp2) {
         switch (NT) {
-            case 4: launch_conv<4, 2>(a, g, s); break;
-            case 3: launch_conv<3, 2>(a, g, s); break;
-            case 2: launch_conv<2, 2>(a, g, s); break;
-            default: launch_conv<1, 2>(a, g, s); break;
+            case 4: BABE_CONV_CASE(4, 2) break;
+            case 3: BABE_CONV_CASE(3, 2) break;
+            case 2: BABE_CONV_CASE(2, 2) break;
+            default: BABE_CONV_CASE(1, 2) break;
         }
     } else {
         switch (NT) {
-            case 4: launch_conv<4, 1>(a, g, s); break;
-            case 3: launch_conv<3, 1>(a, g, s); break;
-            case 2: launch_conv<2, 1>(a, g, s); break;
-            default: launch_conv<1, 1>(a, g, s); break;
+            case 4: BABE_CONV_CASE(4, 1) break;
+            case 3: BABE_CONV_CASE(3, 1) break;
+            case 2: BABE_CONV_CASE(2, 1) break;
+            default: BABE_CONV_CASE(1, 1) break;
         }
     }
+#undef BABE_CONV_CASE
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

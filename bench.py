@@ -81,16 +81,17 @@ def overlap_add(segs, hop, n=CLIP, ola=256):
 
 
 def cpu_baseline(threads):
-    """Oracle (CPU restatement of the reference) timed on one score evaluation of a quarter-length segment
-    of the same workload: fs=44100, L=92092, full-width network. Cost per audio-second is identical to the
-    L=368368 segment (work is proportional to the number of CQT frames, i.e. to L)."""
+    """Oracle (CPU restatement of the reference) timed on one score evaluation of a 1/8-length segment of the
+    same workload: fs=44100, L=46046, full-width network. Cost per audio-second is identical to the
+    L=368368 segment (work is proportional to the number of CQT frames, i.e. to L).  Bounded to <=16
+    threads: with hundreds of threads the many small autograd ops of the reference path get slower."""
     from oracle import edm as E
     from oracle import unet as UN
     from oracle.nsgt import CQT_nsgt as OracleCQT
     from oracle.sampler import OracleBlindSampler
     from babe_amd.networks.cqtdiff_plus import init_state_dict
     torch.set_num_threads(threads)
-    L = 92092
+    L = 46046
     Ns, nd = [64, 96, 96, 128, 128, 256, 256], [2, 3, 4, 5, 6, 7, 7]
     sd = init_state_dict(Ns, nd, seed=0, gate_scale=1.0)
     cqt = OracleCQT(7, 64, "oct", ("kaiser", 1), FS, L)
@@ -108,7 +109,7 @@ def cpu_baseline(threads):
     value = (L / FS) / (evals_per_segment * dt)
     return {"value": value, "unit": "audio-sec/s", "cores": threads, "kind": "port",
             "sample": f"1 of 69 score evaluations (UNet fwd+input-VJP, filter fit, guidance) of a {L}-sample "
-                      f"segment at 44.1 kHz (quarter of the 368368-sample segment, same cost per audio-second), "
+                      f"segment at 44.1 kHz (1/8 of the 368368-sample segment, same cost per audio-second), "
                       f"full-width network, {dt:.1f} s on {threads} threads, extrapolated x69"}
 
 
@@ -223,7 +224,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            rec["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
