@@ -14,6 +14,7 @@
 // per step.  Zero "same" padding is applied at staging time.
 #include "common.h"
 #include "../../include/babe_hip.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -385,10 +386,17 @@ extern "C" int babe_conv2d(const babe_conv_args* ap, void* stream) {
     g.CoutP = (a.Cout + 31) / 32 * 32;
     const int n32 = g.CoutP / 32;
     const int NT = pick_nt(g.CoutP);
-    // positions per block: 256 (WP=2) unless that leaves the chip under-filled
+    // positions per block: measured on MI355X (tools/conv_shapes_bench.py) 128-position blocks (WP=1, 3-4 blocks/CU)
+    // beat 256-position blocks (2/CU) on every wide layer because partial last rounds are cheaper; the
+    // 64-channel layers (NT<=2) run equally fast with either, so they keep the larger tile.
     const long npos = (long)a.F * a.T;
     const long blocks256 = ((npos + 255) / 256) * (n32 / NT) * a.B;
-    const bool wp2 = blocks256 >= 512;
+    bool wp2 = (NT <= 2) && blocks256 >= 1024;
+    {   // debug override: BABE_CONV_WP=1|2 forces the positions-per-wave variant
+        static const char* ov = getenv("BABE_CONV_WP");
+        if (ov && ov[0] == '1') wp2 = false;
+        if (ov && ov[0] == '2') wp2 = true;
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool prof = g_prof.on && !g_prof.paused;
     if (prof) {
