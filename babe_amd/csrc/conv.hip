@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 struct ConvGeom {
-    int CinP, CoutP, pt_log2, pr_log2, tiles_t;
+    int CinP, CoutP, pt_log2, pr_log2, tiles_t, prio_mode;
 };
 
 template <int N> struct AVec;
@@ -46,7 +46,7 @@ template <> struct AVec<4> {
 // Packed weights are permuted inside every BN-wide output-channel tile so that the NT values one lane feeds to
 // its NT MFMAs are contiguous in LDS: channel co0 + nt*32 + l  is stored at  co0 + l*NT + nt.
 template <int NT, int WP, int KC, int KW>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(babe_conv_args a, ConvGeom g) {
+__global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_conv_args a, ConvGeom g) {
     constexpr int BN = NT * 32;
     constexpr int NPOS = 128 * WP;          // output positions per block
     constexpr int TG = 256 / NPOS;          // thread groups that split the KC staged channels
@@ -75,6 +75,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(babe_conv_args a, Con
     const int h = lane >> 5;
     const int l31 = lane & 31;
 
+    if (g.prio_mode) {
+        // de-correlate the co-resident waves of a SIMD: all blocks run the same barrier-separated program and would
+        // otherwise reach their (MFMA-free) staging phases together.  Static priority = hardware wave slot.
+        unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u;   // HW_REG_HW_ID.WAVE_ID[1:0]
+        if (g.prio_mode == 2) {        // one priority per BLOCK (the slot of its first wave)
+            if (threadIdx.x == 0) smem[0] = __uint_as_float(slot);
+            __syncthreads();
+            slot = __builtin_amdgcn_readfirstlane(__float_as_uint(smem[0]));
+            __syncthreads();
+        }
+        if (slot == 1) __builtin_amdgcn_s_setprio(1);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
+        else if (slot == 3) __builtin_amdgcn_s_setprio(3);
+    }
     f32x16 acc[NT][WP];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -202,6 +216,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(babe_conv_args a, Con
 #pragma unroll
                 for (int wp = 0; wp < WP; ++wp) bv[c ^ 1][wp] = Xs[2 * q * XCH + boff[wp] + kw];
             }
+            // keep the LDS reads of the NEXT k-pair ahead of this k-pair's MFMAs (hipcc otherwise sinks them
+            // behind the MFMAs into the same registers and waits lgkmcnt(0) with nothing to overlap)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -382,6 +399,10 @@ extern "C" int babe_conv2d(const babe_conv_args* ap, void* stream) {
                    "conv2d: kernel %dx%d unsupported (need 5x3 or 1x1)", a.KH, a.KW);
     BABE_CHECK_ARG(!a.in2 || (a.cin_split > 0 && a.cin_split < a.Cin), "conv2d: bad cin_split");
     ConvGeom g;
+    {
+        static const char* pm = getenv("BABE_CONV_PRIO");
+        g.prio_mode = pm ? atoi(pm) : 0;
+    }
     g.CinP = (a.Cin + 7) / 8 * 8;
     g.CoutP = (a.Cout + 31) / 32 * 32;
     const int n32 = g.CoutP / 32;

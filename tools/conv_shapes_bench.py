@@ -24,6 +24,9 @@ for i in range(7):
 for d in range(7):
     shapes.append((f"mid.H{d}", 256, 256, 448, 64, 5, 3, 2 ** d, 1))
 tot_f = tot_t = 0
+flt = os.environ.get("SHAPES")
+if flt:
+    shapes = [s for s in shapes if any(s[0].startswith(f) for f in flt.split(","))]
 for name, Cin, Cout, F, T, KH, KW, dil, cnt in shapes:
     x = torch.randn(B, Cin, F, T, device="cuda")
     w = torch.randn(Cout, Cin, KH, KW, device="cuda") / math.sqrt(Cin * KH * KW)
