@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void score_direction_kernel(const float* __res
                                                               const float* __restrict__ g,
                                                               const double* __restrict__ part, int nblk,
                                                               float* __restrict__ d, float t, float xi,
-                                                              float sqrt_len, int shared_norm, int B, long n) {
+                                                              float sqrt_len, int shared_norm, int mode, int B,
+                                                              long n) {
     const int b = blockIdx.y;
     double s2 = 0;
     if (shared_norm) {
@@ -46,16 +47,58 @@ __global__ __launch_bounds__(256) void score_direction_kernel(const float* __res
         for (int i = 0; i < nblk; ++i) s2 += part[(long)b * nblk + i];
     }
     const float normguide = (float)sqrt(s2) / sqrt_len;
-    const float s = xi / (normguide + 1e-6f);
+    const float s = (mode == 0) ? xi / (normguide + 1e-6f) / t : xi / (normguide * t + 1e-6f);
     const float it2 = 1.f / (t * t);
     const long base = (long)b * n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float score = (xden[base + i] - xhat[base + i]) * it2 - s * g[base + i] / t;
+        const float score = (xden[base + i] - xhat[base + i]) * it2 - s * g[base + i];
         d[base + i] = -t * score;
     }
 }
 
+// grid (ceil(L/1024), B): each block produces 1024 outputs from 1024+ntaps-1 inputs staged in LDS
+__global__ __launch_bounds__(256) void fir_same_kernel(const float* __restrict__ x, long x_bs,
+                                                       const float* __restrict__ taps, int ntaps,
+                                                       float* __restrict__ out, long out_bs, int L, int adjoint) {
+    extern __shared__ float sh[];
+    float* st = sh;                 // taps
+    float* sx = sh + ntaps;         // input window
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * 1024;
+    const int padl = (ntaps - 1) / 2;
+    // forward: out[n] = sum_k taps[k] x[n+k-padl]; adjoint: out[m] = sum_k taps[k] g[m-k+padl]
+    const int lo = adjoint ? n0 - (ntaps - 1) + padl : n0 - padl;
+    const int nin = 1024 + ntaps - 1;
+    for (int i = threadIdx.x; i < ntaps; i += blockDim.x) st[i] = taps[i];
+    for (int i = threadIdx.x; i < nin; i += blockDim.x) {
+        const int s = lo + i;
+        sx[i] = (s >= 0 && s < L) ? x[(long)b * x_bs + s] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
+        const int n = n0 + j;
+        if (n >= L) break;
+        float acc = 0.f;
+        if (!adjoint) {
+            for (int k = 0; k < ntaps; ++k) acc += st[k] * sx[j + k];
+        } else {
+            for (int k = 0; k < ntaps; ++k) acc += st[k] * sx[j + (ntaps - 1) - k];
+        }
+        out[(long)b * out_bs + n] = acc;
+    }
+}
+
 }  // namespace
+
+extern "C" int babe_fir_same(const float* x, long x_bs, const float* taps, int ntaps, float* out, long out_bs, int B,
+                             int L, int adjoint, void* stream) {
+    BABE_CHECK_ARG(x && taps && out && B > 0 && L > 0 && ntaps > 0 && ntaps <= 4096, "fir_same: bad arguments");
+    const size_t lds = (size_t)(ntaps + 1024 + ntaps - 1) * sizeof(float);
+    hipLaunchKernelGGL(fir_same_kernel, dim3(cdiv(L, 1024), B), dim3(256), lds, (hipStream_t)stream, x, x_bs, taps,
+                       ntaps, out, out_bs, L, adjoint);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
 
 extern "C" int babe_lincomb3(float* out, float a, const float* x, float b, const float* y, float c, const float* z,
                              long n, void* stream) {
@@ -75,13 +118,13 @@ extern "C" int babe_sumsq_partial(const float* g, long g_bs, double* part, int n
 }
 
 extern "C" int babe_score_direction(const float* xden, const float* xhat, const float* g, const double* part, int nblk,
-                                    float* d, float t, float xi, float audio_len, int shared_norm, int B, long n,
-                                    void* stream) {
+                                    float* d, float t, float xi, float audio_len, int shared_norm, int mode, int B,
+                                    long n, void* stream) {
     BABE_CHECK_ARG(xden && xhat && g && part && d && B > 0 && n > 0 && t > 0, "score_direction: bad arguments");
     int bx = cdiv(n, 1024);
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(score_direction_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, xden, xhat, g, part,
-                       nblk, d, t, xi, sqrtf(audio_len), shared_norm, B, n);
+                       nblk, d, t, xi, sqrtf(audio_len), shared_norm, mode, B, n);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

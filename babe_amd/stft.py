@@ -41,7 +41,8 @@ def _register():
         "babe_filter_fit": [P, P, P, I, I, I, F, I, C.POINTER(FitCfg), P],
         "babe_lincomb3": [P, F, P, F, P, F, P, Lg, P],
         "babe_sumsq_partial": [P, Lg, P, I, I, Lg, P],
-        "babe_score_direction": [P, P, P, P, I, P, F, F, F, I, I, Lg, P],
+        "babe_score_direction": [P, P, P, P, I, P, F, F, F, I, I, I, Lg, P],
+        "babe_fir_same": [P, Lg, P, I, P, Lg, I, I, I, P],
     }
     for n, s in sig.items():
         fn = getattr(L, n)
@@ -55,6 +56,17 @@ def lincomb(out, a, x, b=0.0, y=None, c=0.0, z=None):
     n = x.numel()
     assert x.is_contiguous() and out.is_contiguous() and (y is None or y.is_contiguous()) and (z is None or z.is_contiguous())
     check(lib().babe_lincomb3(ptr(out), a, ptr(x), b, ptr(y), c, ptr(z), n, stream()), "lincomb3")
+    return out
+
+
+def fir_same(x, taps, adjoint=False):
+    """F.conv1d(x[:,None], taps[None,None], padding="same") or its transpose; x [B,L] device, taps [ntaps] device."""
+    _register()
+    B, L = x.shape
+    out = torch.empty_like(x)
+    taps = taps.reshape(-1).contiguous()
+    check(lib().babe_fir_same(ptr(x), x.stride(0), ptr(taps), taps.numel(), ptr(out), out.stride(0), B, L,
+                              int(adjoint), stream()), "fir_same")
     return out
 
 
@@ -107,10 +119,10 @@ class STFTOps:
                              ptr(out), out.stride(0), ptr(part), self.NBLK, B, self.L, self.nfft, self.frames, stream()), "ola")
         return (out, part) if y is not None else out
 
-    def residual_seed(self, r, part):
+    def residual_seed(self, r, part, post=True):
         B = r.shape[0]
         out = torch.empty_like(r)
-        check(lib().babe_residual_seed(ptr(r), r.stride(0), ptr(part), self.NBLK, ptr(self.env_inv), ptr(out),
+        check(lib().babe_residual_seed(ptr(r), r.stride(0), ptr(part), self.NBLK, ptr(self.env_inv) if post else None, ptr(out),
                                        out.stride(0), B, self.L, stream()), "residual_seed")
         return out
 

@@ -21,12 +21,13 @@ high-pass, UNet input-VJP).  All tensor work is C-ABI calls; the host only seque
 """
 import torch
 
-from ..stft import STFTOps, lincomb, make_fit_cfg
+from ..stft import STFTOps, fir_same, lincomb, make_fit_cfg
 from .._lib import check, lib, ptr, stream
 
 
 class BlindSampler:
     NBLK = 64
+    SCORE_MODE = 0          # guidance scaling of blind_bwe_sampler.py:125-135
 
     def __init__(self, model, diff_params, args, rid=False, batch_semantics="per_clip", noise_device="cpu"):
         self.model = model
@@ -61,6 +62,7 @@ class BlindSampler:
                                     only_negative_A=bb.optimization.only_negative_A,
                                     weighting=ps.freq_weighting_filter)
         self._stft = None
+        self.fir_taps = None
 
     def update_diff_params(self):
         dp, src = self.diff_params, self.args.tester.diff_params
@@ -114,15 +116,22 @@ class BlindSampler:
         B, L = x.shape
         x_den = self.get_denoised_estimate(x, t)
         cskip, cout, cin = self._c
-        specX = st.stft(x_den)
-        if blind:
-            filter_params, self.last_n_iter = self.fit_params(specX, specY, filter_params)
-        H = st.design_filter(filter_params)                     # [P,nbins]
-        Hq = H if H.shape[0] == B else H[0]
-        # reconstruction guidance: forward residual and hand-wired VJP
-        r, part = st.ola(st.filter_frames(specX, Hq), normalise=True, y=y)
-        seed = st.residual_seed(r, part)
-        g_den = st.ola(st.filter_frames(st.stft(seed), Hq), normalise=False)
+        if self.fir_taps is not None:
+            # known FIR degradation (edm_sampler.py:245-252): residual, then the transpose FIR
+            rec = fir_same(x_den, self.fir_taps)
+            r = lincomb(torch.empty_like(y), 1.0, y, -1.0, rec)
+            seed = st.residual_seed(r, self._sumsq(r), post=False)
+            g_den = fir_same(seed, self.fir_taps, adjoint=True)
+        else:
+            specX = st.stft(x_den)
+            if blind:
+                filter_params, self.last_n_iter = self.fit_params(specX, specY, filter_params)
+            H = st.design_filter(filter_params)                     # [P,nbins]
+            Hq = H if H.shape[0] == B else H[0]
+            # reconstruction guidance: forward residual and hand-wired VJP
+            r, part = st.ola(st.filter_frames(specX, Hq), normalise=True, y=y)
+            seed = st.residual_seed(r, part)
+            g_den = st.ola(st.filter_frames(st.stft(seed), Hq), normalise=False)
         if self.args.tester.filter_out_cqt_DC_Nyq:
             g_den = cq.apply_hpf_DC(g_den)                      # zero-phase real filter: self-adjoint
         g_net = lincomb(torch.empty_like(g_den), cout, g_den)
@@ -132,7 +141,8 @@ class BlindSampler:
         d = torch.empty_like(x)
         check(lib().babe_score_direction(ptr(x_den), ptr(x), ptr(g_x), ptr(gpart), self.NBLK, ptr(d), float(t),
                                          float(self.xi), float(self.args.exp.audio_len),
-                                         int(self.batch_semantics == "reference"), B, L, stream()), "score_direction")
+                                         int(self.batch_semantics == "reference"), self.SCORE_MODE, B, L, stream()),
+              "score_direction")
         return d, x_den, filter_params
 
     # ------------------------------------------------------------------ sampling loops

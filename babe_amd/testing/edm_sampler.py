@@ -1,0 +1,84 @@
+"""Known-degradation EDM sampler (config #1) on the babe_hip kernels.
+
+Drop-in for the reference's ``testing.edm_sampler.Sampler`` (/root/reference/testing/edm_sampler.py:8-305):
+``Sampler(model, diff_params, args, rid=False)``, ``predict_bwe(ylpf, filt, 'firwin')`` :266-305 ->
+``predict_conditional`` -> ``predict`` :166-229 with ``get_score_rec_guidance`` :56-94.  Differences from
+BlindSampler that matter for parity: the schedule always starts from sigma_max with a pure
+prior sample (:177-179); no noise is drawn on steps with gamma == 0 (:187-198); Snoise scales the noise;
+the guidance scale is xi/(||g||/sqrt(L)*t + 1e-6) without the extra 1/t (:78-92).
+Only the FIR degradation ('firwin' / 'firwin_hpf') runs on the HIP path; IIR/biquad/resample/decimate
+are torchaudio paths that no target config uses.
+"""
+import torch
+
+from ..stft import lincomb
+from .blind_bwe_sampler import BlindSampler
+
+
+class Sampler(BlindSampler):
+    SCORE_MODE = 1
+
+    def __init__(self, model, diff_params, args, rid=False, batch_semantics="per_clip", noise_device="cpu"):
+        self.model = model
+        self.diff_params = diff_params
+        self.args = args
+        if not args.tester.diff_params.same_as_training:
+            self.update_diff_params()
+        self.order = args.tester.order
+        self.xi = args.tester.posterior_sampling.xi
+        self.data_consistency = args.tester.posterior_sampling.data_consistency
+        if self.data_consistency:
+            raise NotImplementedError("data_consistency=True (replacement step) is not on the HIP path")
+        if self.xi <= 0:
+            raise NotImplementedError("xi=0 (no guidance)")
+        self.nb_steps = args.tester.T
+        self.rid = rid
+        self.batch_semantics = batch_semantics
+        self.noise_device = noise_device
+        self._stft = None
+        self.fir_taps = None
+
+    def stft_ops(self, L, device):
+        if self._stft is None or self._stft.L != L:
+            from ..stft import STFTOps
+            self._stft = STFTOps(4096, L, self.args.exp.sample_rate, device)     # only its residual_seed helper is used
+        return self._stft
+
+    def predict_bwe(self, ylpf, filt, filt_type):
+        if filt_type not in ("firwin", "firwin_hpf"):
+            raise NotImplementedError(f"filt_type={filt_type!r}: only FIR degradations run on the HIP path")
+        self.fir_taps = torch.as_tensor(filt, dtype=torch.float32).reshape(-1).contiguous().to(ylpf.device)
+        return self.predict_conditional(ylpf)
+
+    def predict_conditional(self, y):
+        dp = self.diff_params
+        y = y.contiguous().float()
+        B, L = y.shape
+        device = y.device
+        self.stft_ops(L, device)
+        T = self.nb_steps
+        if self.rid:
+            data_denoised = torch.zeros((T, B, L))
+        t = dp.create_schedule(T)
+        x = (self._randn((B, L), device) * float(t[0])).contiguous()
+        gamma = dp.get_gamma(t)
+        for i in range(T):
+            if float(gamma[i]) == 0:
+                t_hat, x_hat = t[i], x
+            else:
+                t_hat = t[i] + gamma[i] * t[i]
+                eps = self._randn((B, L), device).contiguous()
+                x_hat = lincomb(torch.empty_like(x), 1.0, x, float((t_hat ** 2 - t[i] ** 2) ** (1 / 2)) * float(dp.Snoise), eps)
+            d, _, _ = self.evaluate(x_hat, float(t_hat), y, None, None, blind=False)
+            h = float(t[i + 1] - t_hat)
+            if float(t[i + 1]) != 0 and self.order == 2:
+                x_prime = lincomb(torch.empty_like(x), 1.0, x_hat, h, d)
+                d2, _, _ = self.evaluate(x_prime, float(t[i + 1]), y, None, None, blind=False)
+                x = lincomb(torch.empty_like(x), 1.0, x_hat, 0.5 * h, d, 0.5 * h, d2)
+            else:
+                x = lincomb(torch.empty_like(x), 1.0, x_hat, h, d)
+            if self.rid:
+                data_denoised[i] = x.cpu()
+        if self.rid:
+            return x, data_denoised, t
+        return x

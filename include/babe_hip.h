@@ -153,16 +153,25 @@ typedef struct {
 int babe_filter_fit(const double* stats, float* params, int* n_iter, int P, int K, int nbins, float fs, int nfft,
                     const babe_fit_cfg* cfg, void* stream);
 
+/* ---- known FIR degradation (config #1): F.conv1d(y[B,1,L], taps[1,1,ntaps], padding="same"),
+ * testing/edm_sampler.py:245-252, utils/bandwidth_extension.py:76-95.  PyTorch pads (ntaps-1)/2 on the left and the
+ * rest on the right (even ntaps: 249 | 250) and does not flip the kernel: out[n] = sum_k taps[k] x[n+k-padl].
+ * adjoint=1 computes the transpose (the input-VJP). */
+int babe_fir_same(const float* x, long x_bs, const float* taps, int ntaps, float* out, long out_bs, int B, int L,
+                  int adjoint, void* stream);
+
 /* ---- sampler element-wise steps: testing/blind_bwe_sampler.py:503-516, :125-135, :701-761; edm.py:144-159 */
 /* out = a*x + b*y + c*z (y, z optional) over n elements */
 int babe_lincomb3(float* out, float a, const float* x, float b, const float* y, float c, const float* z, long n,
                   void* stream);
 /* part[b][blk] = sum of squares of g[b][blk-th slice] (double) */
 int babe_sumsq_partial(const float* g, long g_bs, double* part, int nblk, int B, long n, void* stream);
-/* d = -t * ((xden - xhat)/t^2 - s_b * g / t),  s_b = xi / (||g_b|| / sqrt(audio_len) + 1e-6);
- * shared_norm=1 uses the norm over the whole batch (reference semantics, :125). */
+/* mode 0 (blind_bwe_sampler.py:125-135,701): d = -t*((xden-xhat)/t^2 - s*g/t), s = xi/(||g||/sqrt(audio_len) + 1e-6)
+ * mode 1 (edm_sampler.py:78-92):              d = -t*((xden-xhat)/t^2 - s*g),   s = xi/(||g||/sqrt(audio_len)*t + 1e-6)
+ * shared_norm=1 uses the norm over the whole batch (reference semantics). */
 int babe_score_direction(const float* xden, const float* xhat, const float* g, const double* part, int nblk,
-                         float* d, float t, float xi, float audio_len, int shared_norm, int B, long n, void* stream);
+                         float* d, float t, float xi, float audio_len, int shared_norm, int mode, int B, long n,
+                         void* stream);
 
 #ifdef __cplusplus
 }

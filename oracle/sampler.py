@@ -79,3 +79,44 @@ class OracleBlindSampler:
             else:
                 x = x_hat + h * d
         return x.detach(), params.detach()
+
+
+class OracleEDMSampler:
+    """Known-FIR-degradation sampler: /root/reference/testing/edm_sampler.py Sampler.predict :166-229,
+    get_score_rec_guidance :56-94, apply_FIR_filter :245-252 (conv1d padding='same', no kernel flip)."""
+
+    def __init__(self, net, cqt, edm_params, *, audio_len, T=35, order=2, xi=0.25, filter_out_cqt_DC_Nyq=True):
+        self.net, self.cqt, self.p = net, cqt, edm_params
+        self.audio_len, self.T, self.order, self.xi, self.hpf = audio_len, T, order, xi, filter_out_cqt_DC_Nyq
+
+    def score(self, x, t, y, taps):
+        x = x.detach().requires_grad_(True)
+        xd = E.denoiser(self.p, self.net, x, t.reshape(1, 1).expand(x.shape[0], 1))
+        if self.hpf:
+            xd = self.cqt.apply_hpf_DC(xd)
+        rec = torch.nn.functional.conv1d(xd.unsqueeze(1), taps.view(1, 1, -1), padding="same").squeeze(1)
+        norm = torch.linalg.norm(y - rec, dim=1, ord=2)
+        g, = torch.autograd.grad(norm.sum(), x)
+        s = self.xi / (torch.linalg.norm(g) / self.audio_len ** 0.5 * t + 1e-6)
+        return (xd.detach() - x.detach()) / t ** 2 - s * g
+
+    def predict_bwe(self, y, taps, noises):
+        p = self.p
+        t = E.schedule(p, self.T)
+        gam = E.gamma(p, t)
+        it = iter(noises)
+        x = next(it) * t[0]
+        for i in range(self.T):
+            if gam[i] == 0:
+                t_hat, x_hat = t[i], x
+            else:
+                t_hat = t[i] + gam[i] * t[i]
+                x_hat = x + ((t_hat ** 2 - t[i] ** 2) ** 0.5) * (next(it) * p.Snoise)
+            d = -t_hat * self.score(x_hat, t_hat, y, taps)
+            h = t[i + 1] - t_hat
+            if t[i + 1] != 0 and self.order == 2:
+                d2 = -t[i + 1] * self.score(x_hat + h * d, t[i + 1], y, taps)
+                x = x_hat + h * (0.5 * d + 0.5 * d2)
+            else:
+                x = x_hat + h * d
+        return x.detach()

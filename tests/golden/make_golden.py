@@ -300,7 +300,56 @@ def g7_8():
     save("sampler_small.npz", **out)
 
 
+# ---------------------------------------------------------------- G9: config #1 (known FIR, edm_sampler)
+def g9():
+    import scipy.signal
+    esm = importlib.import_module("testing.edm_sampler")
+    ube = importlib.import_module("utils.bandwidth_extension")
+    out = {}
+    for fs in (22050, 44100):
+        out[f"taps_{fs}"] = ube.get_FIR_lowpass(500, 1000 if fs == 22050 else 3000, 1, fs)[0, 0]
+    g = torch.Generator().manual_seed(909)
+    x = torch.randn(2, 5000, generator=g)
+    out["fir_x_seed"] = 909
+    out["fir_y"] = ube.apply_low_pass_firwin(x, ube.get_FIR_lowpass(500, 1000, 1, 22050))
+    args = small_args(T=3)
+    import yaml
+    with open(f"{ref_shim.REF}/conf/tester/edm_DC_correction_4s.yaml") as f:
+        args.tester = ref_shim.to_attr(yaml.safe_load(f))
+    args.tester.T = 3
+    net, sd = build_ref_net(args)
+
+    class ResidualNet:
+        def __init__(self, inner, a, sigma_data):
+            self.inner, self.a, self.sd = inner, a, sigma_data
+            self.CQTransform = inner.CQTransform
+
+        def __call__(self, x, cnoise):
+            return self.a * self.inner(x, cnoise) + (torch.exp(4 * cnoise) / self.sd) * x
+
+    with quiet():
+        s = esm.Sampler(ResidualNet(net, 0.3, 0.063), edm_mod.EDM(args), args)
+    L = args.exp.audio_len
+    g = torch.Generator().manual_seed(5151)
+    clean = 0.1 * torch.randn(1, L, generator=g)
+    taps = ube.get_FIR_lowpass(500, 1000, 1, 22050)
+    y = ube.apply_low_pass_firwin(clean, taps)
+    noises = [torch.randn(1, L, generator=g) for _ in range(1 + args.tester.T)]
+    it = iter(noises)
+    orig = torch.randn
+    torch.randn = lambda *a, **k: next(it)
+    try:
+        with quiet(), contextlib.redirect_stderr(io.StringIO()):
+            xr = s.predict_bwe(y.clone(), taps, "firwin")
+    finally:
+        torch.randn = orig
+    out.update(seed=5151, res_a=0.3, y=y, x=xr, xi=args.tester.posterior_sampling.xi,
+               ro=args.tester.diff_params.ro, sigma_max=args.tester.diff_params.sigma_max,
+               Schurn=args.tester.diff_params.Schurn)
+    save("edm_sampler_firwin.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9"]
     for w in which:
         globals()[w]()

@@ -115,3 +115,41 @@ def test_per_clip_batch_equals_single_clip_runs():
         x1, fp1 = smp.predict_blind_bwe(y[b:b + 1].cuda())
         assert rel(xb[b:b + 1], x1) < 1e-4
         assert params_close(fpb[b], fp1)
+
+
+def test_fir_kernel_and_adjoint():
+    from babe_amd.stft import fir_same
+    s = load("edm_sampler_firwin.npz")
+    gen = torch.Generator().manual_seed(int(s["fir_x_seed"]))
+    x = torch.randn(2, 5000, generator=gen)
+    taps = s["taps_22050"]
+    y = fir_same(x.cuda(), taps.cuda())
+    assert rel(y, s["fir_y"]) < 1e-5
+    g = torch.randn(2, 5000, generator=gen)
+    gx = fir_same(g.cuda(), taps.cuda(), adjoint=True)
+    lhs = float((y.double().cpu() * g.double()).sum())
+    rhs = float((x.double() * gx.double().cpu()).sum())
+    assert abs(lhs - rhs) < 1e-4 * (abs(lhs) + abs(rhs)) + 1e-6
+    from babe_amd.utils.bandwidth_extension import get_FIR_lowpass
+    assert torch.equal(get_FIR_lowpass(500, 1000, 1, 22050)[0, 0], taps)
+
+
+def test_edm_sampler_firwin_T3_vs_reference_golden():
+    """Config #1 (known 500-tap FIR, testing/edm_sampler.py) on the HIP path vs the reference's output."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.edm_sampler import Sampler
+    s = load("edm_sampler_firwin.npz")
+    g, args, net = small_net(T=3)
+    args.tester.posterior_sampling.xi = float(s["xi"])
+    args.tester.diff_params.ro = float(s["ro"])
+    args.tester.diff_params.sigma_max = float(s["sigma_max"])
+    args.tester.diff_params.Schurn = float(s["Schurn"])
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    smp = Sampler(ResidualNet(net, float(s["res_a"]), 0.063), EDM(args), args)
+    it = iter(noises)
+    smp._randn = lambda shape, device: next(it).to(device)
+    x = smp.predict_bwe(s["y"].cuda(), s["taps_22050"], "firwin")
+    assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 2e-3

@@ -75,3 +75,34 @@ def test_sampler_T3():
     assert params_close(fp, s["filter_params"])
     xk, _ = smp.predict_blind_bwe(s["y"], noises, blind=False, params=torch.tensor([[2000.0], [-40.0]]))
     assert rel(xk, s["x_known"]) < 1e-3
+
+
+def test_edm_sampler_firwin_T3():
+    """Config #1: known 500-tap Kaiser FIR, edm_sampler.Sampler.predict_bwe('firwin') (G9)."""
+    from oracle.sampler import OracleEDMSampler
+    g, sd, cqt = small_net()
+    s = load("edm_sampler_firwin.npz")
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    a = float(s["res_a"])
+    p = E.EDMParams(0.063, 1e-4, float(s["sigma_max"]), float(s["ro"]), Schurn=float(s["Schurn"]), Stmin=0, Stmax=50, Snoise=1.0)
+    net = lambda x, cn: a * UN.unet_forward(sd, CFG, cqt, x, cn) + (torch.exp(4 * cn) / 0.063) * x
+    smp = OracleEDMSampler(net, cqt, p, audio_len=L, T=3, xi=float(s["xi"]))
+    x = smp.predict_bwe(s["y"], s["taps_22050"], noises)
+    assert rel(x, s["x"]) < 1e-3
+
+
+def test_fir_taps_and_apply():
+    import scipy.signal
+    s = load("edm_sampler_firwin.npz")
+    taps = torch.tensor(scipy.signal.firwin(numtaps=500, cutoff=1000, width=1, window="kaiser", fs=22050), dtype=torch.float32)
+    assert torch.equal(taps, s["taps_22050"])
+    gen = torch.Generator().manual_seed(int(s["fir_x_seed"]))
+    x = torch.randn(2, 5000, generator=gen)
+    y = torch.zeros_like(x)
+    xp = torch.nn.functional.pad(x, (249, 250))
+    for k in range(500):                                   # out[n] = sum_k taps[k] x[n+k-249]
+        y += taps[k] * xp[:, k:k + 5000]
+    assert rel(y, s["fir_y"]) < 1e-5
