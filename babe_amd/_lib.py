@@ -34,6 +34,8 @@ _P, _L, _I, _F = C.c_void_p, C.c_long, C.c_int, C.c_float
 _SIGS = {
     "babe_conv2d": [C.POINTER(ConvArgs), _P],
     "babe_conv_pack_weights": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "babe_conv2d_bf16": [C.POINTER(ConvArgs), _P, _I, _P],
+    "babe_conv_pack_weights_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "babe_gn_partial": [_P, _P, _I, _I, _L, _I, _P],
     "babe_gn_finalize": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _L, _I, _F, _P],
     "babe_scale_gelu": [_P, _P, _P, _I, _I, _L, _P],
@@ -57,6 +59,8 @@ def lib():
         L.babe_version.restype = C.c_char_p
         L.babe_conv_packed_size.restype = C.c_long
         L.babe_conv_packed_size.argtypes = [_I, _I, _I, _I, _I]
+        L.babe_conv_packed_size_bf16.restype = C.c_long
+        L.babe_conv_packed_size_bf16.argtypes = [_I, _I, _I, _I, _I, _I]
         for name, sig in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes = sig

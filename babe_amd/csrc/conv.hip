@@ -371,6 +371,13 @@ static hipEvent_t prof_event() {
     return g_prof.ev[g_prof.used++];
 }
 
+// shared with conv_bf16.hip
+extern "C" void babe_conv_prof_mark(int begin, double flops, void* stream) {
+    if (!(g_prof.on && !g_prof.paused)) return;
+    hipEventRecord(prof_event(), (hipStream_t)stream);
+    if (begin) g_prof.flops += flops;
+}
+
 extern "C" long babe_conv_packed_size(int Cout, int Cin, int KH, int KW, int transpose_flip) {
     const int co = transpose_flip ? Cin : Cout;
     const int ci = transpose_flip ? Cout : Cin;

@@ -111,10 +111,13 @@ class _UnetFn(torch.autograd.Function):
 
 
 class Unet_CQT_oct_with_attention(nn.Module):
-    def __init__(self, args, device):
+    def __init__(self, args, device, precision=None):
         super().__init__()
         self.args = args
         nw = args.network
+        # conv arithmetic: 'f32' (default, the parity path), 'bf16x3', 'bf16' (csrc/conv_bf16.hip); can also be
+        # given as args.network.precision
+        self.precision = precision or nw.get("precision", "f32")
         if nw.get("use_fencoding", False):
             raise NotImplementedError("use_fencoding=True (disabled in the blind-BWE configs)")
         if any(nw.get("attention_layers", [0])):
@@ -140,7 +143,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
     def engine(self):
         if self._engine is None:
             sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in self.state_dict().items()}
-            self._engine = UnetEngine(sd, self.Ns, self.num_dils, self.num_octs, self.bins_per_oct)
+            self._engine = UnetEngine(sd, self.Ns, self.num_dils, self.num_octs, self.bins_per_oct, self.precision)
         return self._engine
 
     def _apply(self, fn, *a, **k):

@@ -23,15 +23,16 @@ RS2 = 1.0 / math.sqrt(2.0)
 class _Block:
     """One ResnetBlock: packed weights + per-call saved tensors."""
 
-    def __init__(self, sd, prefix, num_dils, film_index, proj_after=False):
+    def __init__(self, sd, prefix, num_dils, film_index, proj_after=False, precision="f32"):
         self.p = prefix
         self.nd = num_dils
         self.proj_after = proj_after
         g = lambda k: sd.get(prefix + k)
-        self.proj_in = ops.PackedConv(g("proj_in.weight")) if g("proj_in.weight") is not None else None
-        self.res_conv = ops.PackedConv(g("res_conv.weight")) if g("res_conv.weight") is not None else None
-        self.proj_out = ops.PackedConv(g("proj_out.weight")) if (proj_after and g("proj_out.weight") is not None) else None
-        self.H = [ops.PackedConv(g(f"H.{d}.weight")) for d in range(num_dils)]
+        PC = lambda w: ops.PackedConv(w, precision)
+        self.proj_in = PC(g("proj_in.weight")) if g("proj_in.weight") is not None else None
+        self.res_conv = PC(g("res_conv.weight")) if g("res_conv.weight") is not None else None
+        self.proj_out = PC(g("proj_out.weight")) if (proj_after and g("proj_out.weight") is not None) else None
+        self.H = [PC(g(f"H.{d}.weight")) for d in range(num_dils)]
         self.gamma = [g(f"norm.{d}.gamma").reshape(-1).contiguous() for d in range(num_dils)]
         self.N = self.H[0].Cout
         self.k53 = self.H[0].KH > 1
@@ -65,8 +66,10 @@ class _FilmIndex:
 
 
 class UnetEngine:
-    def __init__(self, sd, Ns, num_dils, num_octs=7, bins_per_oct=64):
-        """sd: dict of DEVICE fp32 tensors with the reference's state_dict key names."""
+    def __init__(self, sd, Ns, num_dils, num_octs=7, bins_per_oct=64, precision="f32"):
+        """sd: dict of DEVICE fp32 tensors with the reference's state_dict key names.
+        precision: conv arithmetic, 'f32' (exact fp32 MFMA, the parity path), 'bf16x3' or 'bf16'."""
+        self.precision = precision
         self.Ns, self.num_dils, self.nocts, self.bpo = list(Ns), list(num_dils), num_octs, bins_per_oct
         self.dev = sd["embedding.RFF_freq"].device
         fi = _FilmIndex()
@@ -74,16 +77,16 @@ class UnetEngine:
         self.rff_freq = sd["embedding.RFF_freq"].reshape(-1).contiguous()
         self.init_blk, self.main_blk, self.pyr_conv = [], [], []
         for i in range(num_octs):
-            self.init_blk.append(_Block(sd, f"downs.{i}.0.", 1, fi))
-            self.pyr_conv.append(ops.PackedConv(sd[f"downs.{i}.1.weight"]))
-            self.main_blk.append(_Block(sd, f"downs.{i}.2.", num_dils[i], fi))
-        self.mid_blk = _Block(sd, "middle.0.1.", num_dils[-1], fi)
-        self.mid_out = _Block(sd, "middle.0.0.", 1, fi, proj_after=True)
+            self.init_blk.append(_Block(sd, f"downs.{i}.0.", 1, fi, precision=precision))
+            self.pyr_conv.append(ops.PackedConv(sd[f"downs.{i}.1.weight"], precision))
+            self.main_blk.append(_Block(sd, f"downs.{i}.2.", num_dils[i], fi, precision=precision))
+        self.mid_blk = _Block(sd, "middle.0.1.", num_dils[-1], fi, precision=precision)
+        self.mid_out = _Block(sd, "middle.0.0.", 1, fi, proj_after=True, precision=precision)
         self.up_out, self.up_blk = [], []
         for i in range(num_octs):
             j = num_octs - 1 - i
-            self.up_out.append(_Block(sd, f"ups.{i}.0.", 1, fi, proj_after=True))
-            self.up_blk.append(_Block(sd, f"ups.{i}.1.", num_dils[j], fi))
+            self.up_out.append(_Block(sd, f"ups.{i}.0.", 1, fi, proj_after=True, precision=precision))
+            self.up_blk.append(_Block(sd, f"ups.{i}.1.", num_dils[j], fi, precision=precision))
         fi.finalize()
         self.film_idx = fi
         self._scratch = {}

@@ -17,10 +17,35 @@ def _view(t):
     return ptr(t), t.stride(0), t.stride(1)
 
 
-class PackedConv:
-    """Conv2d weights packed for babe_conv2d, forward and input-VJP (flipped/transposed) versions."""
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
 
-    def __init__(self, w):
+
+class PackedConv:
+    """Conv2d weights packed for babe_conv2d, forward and input-VJP (flipped/transposed) versions.
+    precision: 'f32' (exact fp32 MFMA), 'bf16' or 'bf16x3' (bf16 MFMA, see csrc/conv_bf16.hip)."""
+
+    def __init__(self, w, precision="f32"):
+        self.precision = precision
+        self.splits = PRECISIONS[precision]
+        if self.splits:
+            self._init_bf16(w)
+            return
+        self._init_f32(w)
+
+    def _init_bf16(self, w):
+        assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 4
+        w = w.contiguous()
+        self.Cout, self.Cin, self.KH, self.KW = w.shape
+        L = lib()
+        nf = L.babe_conv_packed_size_bf16(self.Cout, self.Cin, self.KH, self.KW, 0, self.splits)
+        nb = L.babe_conv_packed_size_bf16(self.Cout, self.Cin, self.KH, self.KW, 1, self.splits)
+        self.fwd = torch.empty(nf, device=w.device, dtype=torch.int16)
+        self.bwd = torch.empty(nb, device=w.device, dtype=torch.int16)
+        for tf, dst in ((0, self.fwd), (1, self.bwd)):
+            check(L.babe_conv_pack_weights_bf16(ptr(w), ptr(dst), self.Cout, self.Cin, self.KH, self.KW, tf, self.splits,
+                                                stream()), "pack_bf16")
+
+    def _init_f32(self, w):
         assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 4
         w = w.contiguous()
         self.Cout, self.Cin, self.KH, self.KW = w.shape
@@ -48,7 +73,8 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
     else:
         a.in2, a.in2_bs, a.in2_cs, a.cin_split = None, 0, 0, Cin
         assert C1 == Cin, (C1, Cin)
-    a.w_packed = ptr(pc.bwd if transpose else pc.fwd)
+    wq = pc.bwd if transpose else pc.fwd
+    a.w_packed = None if pc.splits else ptr(wq)
     assert out.shape == (B, Cout, F, T), (out.shape, (B, Cout, F, T))
     a.out, a.out_bs, a.out_cs = _view(out)
     if res is not None:
@@ -64,7 +90,10 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
     a.alpha, a.rbeta = alpha, rbeta
     a.B, a.Cin, a.Cout, a.F, a.T = B, Cin, Cout, F, T
     a.KH, a.KW, a.dil = pc.KH, pc.KW, dil
-    check(lib().babe_conv2d(C.byref(a), stream()), "conv2d")
+    if pc.splits:
+        check(lib().babe_conv2d_bf16(C.byref(a), ptr(wq), pc.splits, stream()), "conv2d_bf16")
+    else:
+        check(lib().babe_conv2d(C.byref(a), stream()), "conv2d")
     return out
 
 

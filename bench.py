@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--T", type=int, default=35, help="EDM steps (35 = the benchmark; anything else is a debug run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="conv arithmetic: f32 = exact fp32 MFMA (the benchmark's dtype); bf16x3 / bf16 = bf16 MFMA with "
+                         "fp32 storage+accumulation (reported with their own dtype string, never as f32)")
     ap.add_argument("--profile-convs", type=int, default=1)
     a = ap.parse_args()
 
@@ -145,7 +148,7 @@ def main():
     from babe_amd.testing.blind_bwe_sampler import BlindSampler
 
     args = default_args(sample_rate=FS, audio_len=SEG, T=a.T)
-    net = Unet_CQT_oct_with_attention(args, dev)
+    net = Unet_CQT_oct_with_attention(args, dev, precision=a.precision)
     net.load_state_dict(init_state_dict(args.network.Ns, args.network.num_dils, seed=0, gate_scale=1.0))
     sampler = BlindSampler(net, EDM(args), args, batch_semantics="per_clip", noise_device="cuda")
     st = STFTOps(4096, SEG, FS, dev)
@@ -200,11 +203,18 @@ def main():
     if rank == 0:
         value = world * a.steps * CLIP_SEC / dt
         roof = None
+        dtype = {"f32": "f32", "bf16x3": "bf16x3 (bf16 MFMA on hi/lo-split operands, fp32 storage+accumulate)",
+                 "bf16": "bf16 (bf16 MFMA, fp32 storage+accumulate)"}[a.precision]
+        peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "f32" else 2500.0
+        kname = ("conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM dilated conv, fwd + input-VJP)"
+                 if a.precision == "f32" else
+                 "conv_bf16_kernel (v_mfma_f32_32x32x16_bf16; %s products per k-block; achieved counts ALGORITHMIC flops)"
+                 % ("3" if a.precision == "bf16x3" else "1"))
         if a.profile_convs and ms.value > 0:
             ach = fl.value / (ms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                    "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM dilated conv, fwd + input-VJP)",
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "kernel": kname,
                     "launches": nl.value, "avg_launch_us": round(ms.value * 1e3 / max(nl.value, 1), 2),
                     "algorithmic_tflop_per_launch_avg": round(fl.value / max(nl.value, 1) / 1e12, 5),
                     "kernel_time_share_of_step": round(ms.value * 1e-3 / dt, 4)}
@@ -212,13 +222,13 @@ def main():
             "metric": "audio-sec/s (blind BWE, 10 s @ 44.1 kHz clips, 35 EDM steps 2nd order), whole job",
             "value": round(value, 5), "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: one 10 s 44.1 kHz clip per GPU per step = 2 segments x 368368 samples, "
-                                   "blind LPF estimation, T=%d EDM steps (order 2, %d score evaluations), fp32, "
-                                   "CQTDiff+ Ns=[64,96,96,128,128,256,256], random-init weights" % (a.T, 2 * a.T - 1),
+                                   "blind LPF estimation, T=%d EDM steps (order 2, %d score evaluations), %s, "
+                                   "CQTDiff+ Ns=[64,96,96,128,128,256,256], random-init weights" % (a.T, 2 * a.T - 1, a.precision),
                        "segments_per_clip": 2, "segment_len": SEG, "sample_rate": FS, "T": a.T,
                        "parallelism": "clips sharded over %d GPU(s), RCCL all_gather at end of step" % world,
-                       "headline": a.T == 35},
+                       "headline": a.T == 35 and a.precision == "f32"},
             "per_gpu_realtime_factor": round(value / world, 5),
             "output_finite": finite,
             "roofline": roof,

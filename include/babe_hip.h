@@ -41,6 +41,13 @@ int babe_conv2d(const babe_conv_args* a, void* stream);
 int babe_conv_pack_weights(const float* w, float* dst, int Cout, int Cin, int KH, int KW,
                            int transpose_flip, void* stream);
 long babe_conv_packed_size(int Cout, int Cin, int KH, int KW, int transpose_flip);
+/* bf16-MFMA variants (fp32 tensors in HBM, bf16 operands, fp32 accumulate): splits=1 plain bf16 (configs #3-#5),
+ * splits=2 "bf16x3" (hi/lo split of both operands, three products: 16-bit-mantissa multiplies).
+ * w_bf16 from babe_conv_pack_weights_bf16: [splits][KH][KW][ceil16(Cin)/8][ceil32(Cout)][8] bf16. */
+int babe_conv2d_bf16(const babe_conv_args* a, const void* w_bf16, int splits, void* stream);
+int babe_conv_pack_weights_bf16(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
+                                int splits, void* stream);
+long babe_conv_packed_size_bf16(int Cout, int Cin, int KH, int KW, int transpose_flip, int splits);
 /* Measurement hook (bench.py): when enabled every babe_conv2d launch is bracketed by HIP events on its
  * stream; read returns the summed kernel time, the summed ALGORITHMIC flops (2*B*Cout*Cin*KH*KW*F*T with the
  * unpadded channel counts) and the launch count, then resets. */

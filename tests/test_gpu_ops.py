@@ -60,6 +60,40 @@ def test_conv2d_fwd_and_vjp(ops, B, Cin, Cout, Fq, T, kh, kw, dil):
     assert rel(gx, gref) < 2e-6
 
 
+@pytest.mark.parametrize("precision,tol", [("bf16", 1.5e-2), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("B,Cin,Cout,Fq,T,kh,kw,dil", [
+    (1, 8, 16, 64, 32, 5, 3, 1),
+    (2, 16, 16, 128, 16, 5, 3, 4),
+    (1, 96, 96, 128, 64, 5, 3, 64),
+    (2, 2, 8, 64, 24, 1, 1, 1),
+    (1, 16, 2, 64, 40, 1, 1, 1),
+    (1, 2, 64, 192, 128, 5, 3, 1),
+    (1, 128, 256, 70, 100, 5, 3, 8),
+    (1, 256, 128, 64, 64, 1, 1, 1),
+    (2, 64, 64, 64, 1024, 5, 3, 2),
+])
+def test_conv2d_bf16_variants(ops, precision, tol, B, Cin, Cout, Fq, T, kh, kw, dil):
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + T)
+    x = torch.randn(B, Cin, Fq, T, generator=g)
+    w = torch.randn(Cout, Cin, kh, kw, generator=g) / math.sqrt(Cin * kh * kw)
+    ref = UN.conv_same(x.double(), w.double(), dil)
+    pc = ops.PackedConv(w.cuda(), precision)
+    res = torch.randn(B, Cout, Fq, T, generator=g)
+    osc = torch.randn(B, Cout, generator=g)
+    out = res.cuda().clone()
+    ops.conv2d(x.cuda(), pc, out, dil=dil, res=out, oscale=osc.cuda(), alpha=0.7, rbeta=0.3)
+    ref2 = 0.7 * ref * osc[:, :, None, None].double() + 0.3 * res.double()
+    assert rel(out, ref2) < tol
+    gy = torch.randn(B, Cout, Fq, T, generator=g)
+    isc = torch.randn(B, Cout, generator=g)
+    xr = x.double().requires_grad_(True)
+    y = UN.conv_same(xr, w.double(), dil)
+    gref, = torch.autograd.grad((y * (gy * isc[:, :, None, None]).double()).sum(), xr)
+    gx = torch.empty(B, Cin, Fq, T, device="cuda")
+    ops.conv2d(gy.cuda(), pc, gx, dil=dil, transpose=True, in_scale=isc.cuda())
+    assert rel(gx, gref) < tol
+
+
 def test_conv2d_two_sources_and_views(ops):
     g = torch.Generator().manual_seed(5)
     x1 = torch.randn(2, 16, 64, 32, generator=g)

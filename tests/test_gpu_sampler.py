@@ -25,13 +25,13 @@ def rms_err(a, b):
     return float((a.detach().double().cpu() - b.double().cpu()).pow(2).mean().sqrt())
 
 
-def small_net(T=3, start_sigma=0.05):
+def small_net(T=3, start_sigma=0.05, precision="f32"):
     from babe_amd.config import default_args
     from babe_amd.networks.cqtdiff_plus import Unet_CQT_oct_with_attention
     g = load("unet_small.npz")
     sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
     args = default_args(sample_rate=22050, audio_len=92092, Ns=[8, 8, 8, 8, 16, 16, 16], T=T, start_sigma=start_sigma)
-    net = Unet_CQT_oct_with_attention(args, "cuda")
+    net = Unet_CQT_oct_with_attention(args, "cuda", precision=precision)
     missing = net.load_state_dict(sd, strict=True)
     return g, args, net
 
@@ -153,3 +153,32 @@ def test_edm_sampler_firwin_T3_vs_reference_golden():
     smp._randn = lambda shape, device: next(it).to(device)
     x = smp.predict_bwe(s["y"].cuda(), s["taps_22050"], "firwin")
     assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 2e-3
+
+
+@pytest.mark.parametrize("precision,tol_y,tol_g", [("bf16x3", 1e-4, 1e-3), ("bf16", 2e-2, 6e-2)])
+def test_unet_reduced_precision_modes_vs_reference_golden(precision, tol_y, tol_g):
+    """bf16-MFMA conv modes (fp32 storage and accumulation): stated, looser tolerances."""
+    g, args, net = small_net(precision=precision)
+    gen = torch.Generator().manual_seed(int(g["unet_seed"]))
+    x = (0.1 * torch.randn(1, 92092, generator=gen)).cuda().requires_grad_(True)
+    y = net(x, g["unet_cnoise"].cuda())
+    assert rel(y, g["unet_y"]) < tol_y
+    wv = torch.randn(y.shape, generator=gen)
+    gx, = torch.autograd.grad((y * wv.cuda()).sum(), x)
+    assert rel(gx, g["unet_gx"]) < tol_g
+
+
+def test_blind_sampler_bf16x3_meets_fp32_parity_bar():
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    s = load("sampler_small.npz")
+    g, args, net = small_net(T=3, start_sigma=float(s["start_sigma"]), precision="bf16x3")
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    smp = BlindSampler(ResidualNet(net, float(s["res_a"]), 0.063), EDM(args), args)
+    it = iter(noises)
+    smp._randn = lambda shape, device: next(it).to(device)
+    x, fp = smp.predict_blind_bwe(s["y"].cuda())
+    assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 5e-3

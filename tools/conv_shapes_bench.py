@@ -30,7 +30,7 @@ if flt:
 for name, Cin, Cout, F, T, KH, KW, dil, cnt in shapes:
     x = torch.randn(B, Cin, F, T, device="cuda")
     w = torch.randn(Cout, Cin, KH, KW, device="cuda") / math.sqrt(Cin * KH * KW)
-    pc = ops.PackedConv(w)
+    pc = ops.PackedConv(w, os.environ.get('PRECISION', 'f32'))
     out = torch.empty(B, Cout, F, T, device="cuda")
     for _ in range(2):
         ops.conv2d(x, pc, out, dil=dil)
