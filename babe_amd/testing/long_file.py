@@ -1,0 +1,77 @@
+"""Long-recording driver: fixed-length segments + Hann cross-fade, as the reference's harness does it.
+
+Restates the non-AR path of ``BlindTester.formal_test_bwe`` (/root/reference/testing/blind_bwe_tester.py:
+421-566): segments of ``exp.audio_len`` samples starting every ``segL - discard_end - OLA`` samples
+(discard_end = 200, ``tester.formal_test.OLA`` = 256), the last one zero-padded; each restored segment keeps
+its first ``segL - discard_end`` samples, is faded with the two halves of a 2*OLA Hann window and
+overlap-added.  The reference restores the segments one at a time; they are independent, so here they are
+batched (per-clip semantics) and can be sharded over GPUs.  Host-side plumbing only (slicing / cross-fade);
+the sampler does the work.
+"""
+import torch
+
+
+def plan_segments(L, segL, discard_end=200, ola=256):
+    """[(start, n_valid)] : start sample of each segment and how many of its samples exist in the file."""
+    hop = segL - discard_end - ola
+    starts = [0]
+    ix = hop
+    while ix < L - segL - discard_end:          # :469 (discard_start = 0)
+        starts.append(ix)
+        ix += hop
+    if L > segL - discard_end - ola or len(starts) == 1:
+        starts.append(ix)                        # the final, possibly short, segment (:521-566)
+    if starts[-1] >= L:                          # file shorter than one hop: a single (padded) segment
+        starts = [0]
+    return [(s, min(segL, L - s)) for s in starts]
+
+
+def cut_segments(y, segL, plan):
+    """y [L] -> [S, segL] (zero-padded tail)."""
+    segs = torch.zeros(len(plan), segL, device=y.device, dtype=y.dtype)
+    for i, (s, n) in enumerate(plan):
+        segs[i, :n] = y[s:s + n]
+    return segs
+
+
+def assemble(preds, plan, L, segL, discard_end=200, ola=256):
+    """Cross-fade the restored segments [S, segL] back into a file of L samples."""
+    out = torch.zeros(L, device=preds.device, dtype=preds.dtype)
+    w = torch.hann_window(2 * ola, device=preds.device, dtype=preds.dtype)
+    S = len(plan)
+    for i, (s, n) in enumerate(plan):
+        last = i == S - 1
+        keep = n if last else segL - discard_end
+        if S == 1:
+            keep = min(n, L)
+        p = preds[i, :keep].clone()
+        if i > 0:
+            p[:ola] *= w[:ola]
+        if not last:
+            p[-ola:] *= w[ola:]
+        end = min(s + keep, L)
+        out[s:end] += p[: end - s]
+    return out
+
+
+def restore_file(sampler, y, batch_size=8, blind=True, filt=None):
+    """y [L] device tensor -> (restored [L], [(start, end, filter_params)]) using sampler.predict_blind_bwe
+    (or predict_bwe(filt, 'fc_A') when blind=False) on batches of segments."""
+    segL = sampler.args.exp.audio_len
+    ola = sampler.args.tester.get("formal_test", {}).get("OLA", 256) if hasattr(sampler.args.tester, "get") else 256
+    L = y.shape[-1]
+    plan = plan_segments(L, segL, 200, ola)
+    segs = cut_segments(y, segL, plan)
+    preds, filters = [], []
+    for i in range(0, segs.shape[0], batch_size):
+        chunk = segs[i:i + batch_size].contiguous()
+        if blind:
+            x, fp = sampler.predict_blind_bwe(chunk)
+            fp = fp if fp.dim() == 3 else fp.unsqueeze(0).expand(chunk.shape[0], -1, -1)
+            filters += [fp[j] for j in range(chunk.shape[0])]
+        else:
+            x = sampler.predict_bwe(chunk, filt, "fc_A")
+        preds.append(x)
+    preds = torch.cat(preds, 0)
+    out = assemble(preds, plan, L, segL, 200, ola)
+    return out, [((s, s + segL), f) for (s, _), f in zip(plan, filters)]

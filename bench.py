@@ -5,8 +5,8 @@ Metric (BASELINE.json): audio-seconds restored per wall-second, 10 s @ 44.1 kHz 
 steps (2nd order, 69 score evaluations), blind low-pass estimation; whole-job aggregate over
 all ranks.  One "step" = ONE 10 s clip per GPU through BlindSampler.predict_blind_bwe: the clip is
 cut into two 368368-sample segments (the reference's model length, conf/exp/maestro44k_8s.yaml:52;
-segmentation as formal_test_bwe, testing/blind_bwe_tester.py:421-469) that run as one batch of 2
-with per-clip semantics.  Weak scaling: every rank restores its own clips; one RCCL all_gather of
+segmentation and cross-fade as formal_test_bwe, testing/blind_bwe_tester.py:421-566, restated in
+babe_amd/testing/long_file.py) that run as one batch of 2 with per-clip semantics.  Weak scaling: every rank restores its own clips; one RCCL all_gather of
 the restored audio + filters closes each step.
 
 Usage:  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
@@ -56,30 +56,6 @@ def synth_clip(clip_id, n=CLIP, fs=FS):
     return x.float()
 
 
-def segment_clip(y):
-    """[CLIP] -> [2, SEG]: hop = SEG - 200 - 256 as in formal_test_bwe; the tail is zero-padded."""
-    hop = SEG - 200 - 256
-    segs = torch.zeros(2, SEG, device=y.device)
-    segs[0] = y[:SEG]
-    rest = y[hop:]
-    segs[1, : rest.numel()] = rest
-    return segs, hop
-
-
-def overlap_add(segs, hop, n=CLIP, ola=256):
-    """Hann cross-fade of `ola` samples between consecutive segments (blind_bwe_tester.py:455-499)."""
-    out = torch.zeros(hop + SEG, device=segs.device)
-    w = torch.hann_window(2 * ola, device=segs.device)
-    s0 = segs[0].clone()
-    s0[hop + ola:] = 0
-    s0[hop: hop + ola] *= w[ola:]
-    s1 = segs[1].clone()
-    s1[:ola] *= w[:ola]
-    out[:SEG] += s0
-    out[hop:] += s1
-    return out[:n]
-
-
 def cpu_baseline(threads):
     """Oracle (CPU restatement of the reference) timed on one score evaluation of a 1/8-length segment of the
     same workload: fs=44100, L=46046, full-width network. Cost per audio-second is identical to the
@@ -120,6 +96,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--T", type=int, default=35, help="EDM steps (35 = the benchmark; anything else is a debug run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clips-per-gpu", type=int, default=1,
+                    help="10 s clips restored per GPU per step (1 = the benchmark's single-clip workload; larger values "
+                         "batch more independent segments per kernel launch, cf. configs[2])")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="conv arithmetic: f32 = exact fp32 MFMA (the benchmark's dtype); bf16x3 / bf16 = bf16 MFMA with "
                          "fp32 storage+accumulation (reported with their own dtype string, never as f32)")
@@ -146,6 +125,7 @@ def main():
     from babe_amd.networks.cqtdiff_plus import Unet_CQT_oct_with_attention, init_state_dict
     from babe_amd.stft import STFTOps
     from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    from babe_amd.testing.long_file import assemble, cut_segments, plan_segments
 
     args = default_args(sample_rate=FS, audio_len=SEG, T=a.T)
     net = Unet_CQT_oct_with_attention(args, dev, precision=a.precision)
@@ -154,13 +134,18 @@ def main():
     st = STFTOps(4096, SEG, FS, dev)
     Hlp = st.design_filter(torch.tensor([[10000.0], [-60.0]], device=dev))
 
+    plan = plan_segments(CLIP, SEG)                           # a 10 s clip = 2 segments (reference segmentation)
+    nseg = len(plan)
+    C_ = a.clips_per_gpu
+
     def make_inputs(step):
-        clip_id = step * world + rank
-        x = synth_clip(clip_id).to(dev)
-        x = x * (0.1 / x.std())
-        segs, hop = segment_clip(x)
-        y = st.apply_filter(segs, Hlp)                       # "22.05 kHz content": nothing above ~11 kHz
-        return y, hop
+        ys = []
+        for c in range(C_):
+            clip_id = (step * world + rank) * C_ + c
+            x = synth_clip(clip_id).to(dev)
+            x = x * (0.1 / x.std())
+            ys.append(st.apply_filter(cut_segments(x, SEG, plan), Hlp))   # "22.05 kHz content": nothing above ~11 kHz
+        return torch.cat(ys, 0).contiguous()
 
     torch.manual_seed(2000 + rank)
     torch.cuda.manual_seed(2000 + rank)
@@ -168,10 +153,10 @@ def main():
     inputs = [make_inputs(s) for s in range(nsteps)]          # resident in HBM before the timed region
 
     def one_step(s):
-        y, hop = inputs[s]
-        x, fp = sampler.predict_blind_bwe(y)
-        clip = overlap_add(x, hop)
-        return gather_results(clip.unsqueeze(0), fp.reshape(1, -1)) if world > 1 else (clip, fp)
+        x, fp = sampler.predict_blind_bwe(inputs[s])
+        clips = torch.stack([assemble(x[c * nseg:(c + 1) * nseg], plan, CLIP, SEG) for c in range(C_)])
+        fpc = fp.reshape(C_, -1)
+        return gather_results(clips, fpc) if world > 1 else (clips, fpc)
 
     for s in range(a.warmup):
         one_step(s)
@@ -201,7 +186,7 @@ def main():
     finite = bool(torch.isfinite(out[0]).all())
 
     if rank == 0:
-        value = world * a.steps * CLIP_SEC / dt
+        value = world * a.steps * C_ * CLIP_SEC / dt
         roof = None
         dtype = {"f32": "f32", "bf16x3": "bf16x3 (bf16 MFMA on hi/lo-split operands, fp32 storage+accumulate)",
                  "bf16": "bf16 (bf16 MFMA, fp32 storage+accumulate)"}[a.precision]
@@ -226,9 +211,9 @@ def main():
             "config": {"workload": "configs[1]: one 10 s 44.1 kHz clip per GPU per step = 2 segments x 368368 samples, "
                                    "blind LPF estimation, T=%d EDM steps (order 2, %d score evaluations), %s, "
                                    "CQTDiff+ Ns=[64,96,96,128,128,256,256], random-init weights" % (a.T, 2 * a.T - 1, a.precision),
-                       "segments_per_clip": 2, "segment_len": SEG, "sample_rate": FS, "T": a.T,
+                       "segments_per_clip": nseg, "clips_per_gpu_per_step": C_, "segment_len": SEG, "sample_rate": FS, "T": a.T,
                        "parallelism": "clips sharded over %d GPU(s), RCCL all_gather at end of step" % world,
-                       "headline": a.T == 35 and a.precision == "f32"},
+                       "headline": a.T == 35 and a.precision == "f32" and C_ == 1},
             "per_gpu_realtime_factor": round(value / world, 5),
             "output_finite": finite,
             "roofline": roof,

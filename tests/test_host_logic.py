@@ -1,0 +1,113 @@
+"""Host-side logic of the product (no GPU needed): band design vs the oracle, EDM host class vs golden,
+config loader, FFT factorisation, parameter inventory."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(G, name)).items()}
+
+
+@pytest.mark.parametrize("fs,L", [(22050, 92092), (44100, 368368), (16000, 184184)])
+def test_band_design_matches_oracle(fs, L):
+    from babe_amd.cqt import design_bands, factor_len
+    from oracle.nsgt import CQT_nsgt
+    d = design_bands(fs, L)
+    o = CQT_nsgt(7, 64, "oct", ("kaiser", 1), fs, L, dtype=torch.float64)
+    assert np.array_equal(d["M"], o.design["M"]) and np.array_equal(d["c"], o.design["c"]) and np.array_equal(d["T"], o.design["T"])
+    assert np.allclose(d["hpf"], o.Hhpf_full[: L // 2 + 1].numpy(), atol=1e-14)
+    # window tables: band k of the product == row of the oracle's per-octave table
+    for k in (0, 63, 64, 200, 447):
+        j, i = divmod(k, 64)
+        Mk = int(d["M"][k])
+        w = d["g"][d["woff"][k]: d["woff"][k] + Mk]
+        assert np.allclose(w, o.octs[j]["win"][i, :Mk].numpy(), atol=1e-14)
+        gd = d["gdual"][d["woff"][k]: d["woff"][k] + Mk] * d["T"][k]
+        assert np.allclose(gd, o.octs[j]["dwin"][i, :Mk].numpy(), rtol=1e-12)
+    # CSR covers every window sample exactly once
+    assert d["rowptr"][-1] == d["nwin"] and len(np.unique(d["src"] & 0x7FFFFFFF)) == d["nwin"]
+    N1, N2 = factor_len(L)
+    assert N1 * N2 == L and N2 <= 4096
+
+
+def test_factor_len_rejects_unbalanced():
+    from babe_amd.cqt import factor_len
+    with pytest.raises(ValueError):
+        factor_len(2 * 100003)       # 2 x prime
+
+
+@pytest.mark.parametrize("name", ["formal", "brass", "train"])
+def test_edm_host_class_vs_golden(name):
+    from babe_amd.config import to_attr
+    from babe_amd.diff_params.edm import EDM
+    g = load("edm.npz")
+    c = {k: float(g[f"{name}_cfg_{k}"]) for k in ("sigma_data", "sigma_min", "sigma_max", "ro", "Schurn", "Stmin", "Stmax", "Snoise")}
+    e = EDM(to_attr(dict(diff_params=dict(c, P_mean=-1.2, P_std=1.2, ro_train=10, aweighting=dict(use_aweighting=False)))))
+    for N in (3, 35):
+        t = e.create_schedule(N)
+        assert torch.equal(t, g[f"{name}_sched_{N}"])
+        assert torch.equal(e.create_schedule_from_initial_t(0.2, N), g[f"{name}_sched0_{N}"])
+        assert torch.equal(e.get_gamma(t), g[f"{name}_gamma_{N}"])
+    s = g[f"{name}_sig"]
+    for fn in ("cskip", "cout", "cin", "cnoise"):
+        assert torch.allclose(getattr(e, fn)(s), g[f"{name}_{fn}"], rtol=1e-6, atol=0)
+
+
+def test_config_loader_coerces_exponent_floats(tmp_path):
+    from babe_amd.config import default_args, load_yaml
+    p = tmp_path / "c.yaml"
+    p.write_text("a: 1e-4\nb: {c: 5e-3, d: 'None', e: nyquist}\nl: [1e-8, 2]\n")
+    c = load_yaml(str(p))
+    assert c.a == 1e-4 and c.b.c == 5e-3 and c.b.d == "None" and c.b.e == "nyquist" and c.l == [1e-8, 2]
+    a = default_args()
+    assert a.tester.blind_bwe.optimization.mu == [1000, 10] and a.exp.audio_len == 368368 and a.tester.T == 35
+
+
+def test_parameter_inventory_matches_reference_counts():
+    from babe_amd.networks.cqtdiff_plus import init_state_dict, param_specs
+    specs = param_specs([64, 96, 96, 128, 128, 256, 256], [2, 3, 4, 5, 6, 7, 7])
+    assert len(specs) == 606
+    n = sum(int(np.prod(s)) for k, s, _ in specs if not k.endswith(".kernel"))
+    assert abs(n / 1e6 - 44.499) < 0.01                             # 44.50 M parameters
+    g = load("unet_small.npz")
+    ref = {k[3:]: tuple(v.shape) for k, v in g.items() if k.startswith("sd.")}
+    mine = {k: tuple(v.shape) for k, v in init_state_dict([8, 8, 8, 8, 16, 16, 16], [2, 3, 4, 5, 6, 7, 7]).items()}
+    assert ref == mine
+
+
+def test_product_refuses_cpu_device():
+    from babe_amd.config import default_args
+    from babe_amd.networks.cqtdiff_plus import Unet_CQT_oct_with_attention
+    with pytest.raises(RuntimeError):
+        Unet_CQT_oct_with_attention(default_args(sample_rate=22050, audio_len=92092), "cpu")
+
+
+def test_product_never_imports_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "babe_amd")
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f
+
+
+@pytest.mark.parametrize("L", [441000, 368368 * 3 + 777, 368368, 100000])
+def test_long_file_segmentation_and_crossfade(L):
+    """Identity 'restoration' must reproduce the file: the Hann halves of the cross-fade sum to one."""
+    from babe_amd.testing.long_file import assemble, cut_segments, plan_segments
+    segL = 368368
+    plan = plan_segments(L, segL)
+    hop = segL - 200 - 256
+    assert plan[0][0] == 0 and all(b[0] - a[0] == hop for a, b in zip(plan, plan[1:]))
+    assert plan[-1][0] + plan[-1][1] == L or len(plan) == 1
+    if L == 441000:
+        assert [s for s, _ in plan] == [0, hop]          # a 10 s clip is 2 segments (bench.py workload)
+    y = torch.randn(L, generator=torch.Generator().manual_seed(L % 1000))
+    segs = cut_segments(y, segL, plan)
+    out = assemble(segs, plan, L, segL)
+    assert torch.allclose(out, y, atol=1e-6)
