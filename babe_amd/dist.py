@@ -28,8 +28,13 @@ def gather_results(x_local, fp_local, n_total=None):
     buf = torch.zeros(bmax, L + P, device=x_local.device, dtype=torch.float32)
     buf[: x_local.shape[0], :L] = x_local
     buf[: x_local.shape[0], L:] = fp_local
-    out = torch.empty(world * bmax, L + P, device=x_local.device, dtype=torch.float32)
-    dist.all_gather_into_tensor(out, buf)
+    if dist.get_backend() == "gloo":                    # gloo has no all_gather_into_tensor for device tensors
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        out = torch.cat(parts, 0)
+    else:
+        out = torch.empty(world * bmax, L + P, device=x_local.device, dtype=torch.float32)
+        dist.all_gather_into_tensor(out, buf)
     rows = [out[r * bmax: r * bmax + counts[r]] for r in range(world)]
     allr = torch.cat(rows, 0)
     return allr[:, :L].contiguous(), allr[:, L:].contiguous()

@@ -142,8 +142,9 @@ class UnetEngine:
         blk.saved = saved
         return out
 
-    def block_vjp(self, blk, g_out, g_in, accumulate=False):
-        """g_in (+)= VJP of the block w.r.t. its (concatenated) input. g_out: [B,Cout,F,T] (may be strided)."""
+    def block_vjp(self, blk, g_out, g_in, accumulate=False, consume=False):
+        """g_in (+)= VJP of the block w.r.t. its (concatenated) input. g_out: [B,Cout,F,T] (may be strided).
+        consume=True: g_out is a dense buffer owned by the caller that may be overwritten (saves a full copy)."""
         B, _, Fq, T = g_out.shape
         N = blk.N
         beta = 1.0 if accumulate else 0.0
@@ -152,9 +153,13 @@ class UnetEngine:
             ops.conv2d(g_out, blk.res_conv, g_in, transpose=True, alpha=RS2, rbeta=beta, res=g_in if accumulate else None)
         else:
             ops.axpby(g_out, g_in, alpha=RS2, beta=beta)
-        # main path: gradient w.r.t. z_last
+        # main path: gradient w.r.t. z_last.  The chain below is linear in gz, so the 1/sqrt2 of the block's
+        # output merge is carried as a scalar `c` and applied once at the end instead of scaling a copy.
+        c = 1.0
         if blk.proj_out is not None:
             gz = ops.conv2d(g_out, blk.proj_out, self.buf(B, N, Fq, T), transpose=True, alpha=RS2)
+        elif consume and g_out.is_contiguous():
+            gz, c = g_out, RS2
         else:
             gz = ops.axpby(g_out, self.buf(B, N, Fq, T), alpha=RS2)
         da = self.scratch("a", B * N * Fq * T).view(B, N, Fq, T)
@@ -163,9 +168,9 @@ class UnetEngine:
             ops.conv2d(gz, blk.H[d], da, dil=blk.dil(d), transpose=True, in_scale=gate, alpha=RS2)
             ops.gn_bwd(z, da, gz, scale, stats, gz, RS2)
         if blk.proj_in is not None:
-            ops.conv2d(gz, blk.proj_in, g_in, transpose=True, res=g_in, alpha=1.0, rbeta=1.0)
+            ops.conv2d(gz, blk.proj_in, g_in, transpose=True, res=g_in, alpha=c, rbeta=1.0)
         else:
-            ops.axpby(gz, g_in, alpha=1.0, beta=1.0)
+            ops.axpby(gz, g_in, alpha=c, beta=1.0)
         blk.saved = None
         return g_in
 
@@ -245,17 +250,17 @@ class UnetEngine:
                 accumulate = False
             # O_j = up_out(R_j) entered Xout as rs2*O_j
             gO = ops.axpby(gXOp, self.buf(B, 2, Fj, Ts[j]), alpha=RS2)
-            self.block_vjp(self.up_out[i], gO, gR, accumulate=accumulate)
-            gXO_prev = ops.axpby(gXOp, gXOp, alpha=RS2) if False else ops.axpby(gXOp, self.buf(B, 2, Fj, Ts[j]), alpha=RS2)
+            self.block_vjp(self.up_out[i], gO, gR, accumulate=accumulate, consume=True)
+            gXO_prev = ops.axpby(gXOp, self.buf(B, 2, Fj, Ts[j]), alpha=RS2)
             gcat = self.buf(B, 2 * Ns[j], Fj, Ts[j])
-            self.block_vjp(self.up_blk[i], gR, gcat)
+            self.block_vjp(self.up_blk[i], gR, gcat, consume=True)
             gX_prev = gcat[:, :Ns[j]]
             gH[j] = gcat[:, Ns[j]:]
         # middle: Xout_6 = mid_out(M); X_6 = M
         gM = self.buf(B, Ns[-1], bpo * n, Ts[-1])
         ops.axpby(gX_prev, gM)
-        self.block_vjp(self.mid_out, gXO_prev, gM, accumulate=True)
-        gXm = self.block_vjp(self.mid_blk, gM, self.buf(*gM.shape))
+        self.block_vjp(self.mid_out, gXO_prev, gM, accumulate=True, consume=True)
+        gXm = self.block_vjp(self.mid_blk, gM, self.buf(*gM.shape), consume=True)
         # encoder
         gC = [None] * n
         gpyr_next = None                   # gradient flowing into pyr_i from level i+1
@@ -276,7 +281,7 @@ class UnetEngine:
                 ops.conv2d(gP, self.pyr_conv[i], gpyr, transpose=True, alpha=RS2,
                            res=gpyr_next if gpyr_next is not None else None, rbeta=1.0 if gpyr_next is not None else 0.0)
             Nin = Ns[max(i - 1, 0)]
-            gXC = self.block_vjp(self.main_blk[i], gHi, self.buf(B, Nin, Fi, Ts[i]))
+            gXC = self.block_vjp(self.main_blk[i], gHi, self.buf(B, Nin, Fi, Ts[i]), consume=True)
             gCi = self.buf(B, 2, bpo, Ts[i])
             self.block_vjp(self.init_blk[i], gXC[:, :, :bpo, :], gCi)
             gP = gXC[:, :, bpo:, :] if i > 0 else None

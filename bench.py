@@ -110,11 +110,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_idx = local_rank % max(ndev, 1)          # (== local_rank on a real N-GPU node; lets 2 ranks share 1 GPU in tests)
+    torch.cuda.set_device(dev_idx)
+    dev = torch.device("cuda", dev_idx)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("BABE_DIST_BACKEND", "nccl")      # "gloo" only for the shared-GPU functional test
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     ge.build()
