@@ -1,0 +1,31 @@
+"""HBM-roofline check of the CQT kernels (north star: >= 60 % of HBM bandwidth on the CQT kernel).
+Algorithmic bytes per clip: analysis reads the 1.47 MB half spectrum and writes 4.16 MB of
+coefficients (520192 complex); synthesis the reverse."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from babe_amd.cqt import CQT_nsgt
+
+L, fs = 368368, 44100
+cq = CQT_nsgt(7, 64, "oct", ("kaiser", 1), fs, L, device="cuda")
+ncoef = sum(64 * T for T in cq.T_oct)
+for B in (1, 2, 8, 32, 64):
+    x = torch.randn(B, L, device="cuda")
+    spec = cq.fft.rfft(x)
+    coefs = cq.alloc_coefs(B)
+    def timeit(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    t_an = timeit(lambda: cq.analysis(spec, cq.win_fwd, coefs))
+    t_sy = timeit(lambda: cq.synthesis_spec(coefs, cq.win_bwd, 2.0 / L))
+    t_fft = timeit(lambda: cq.fft.rfft(x))
+    by = B * ((L // 2 + 1) * 8 + ncoef * 8)
+    print(f"B={B:3d} analysis {t_an*1e3:8.1f} us {by/t_an/1e6:8.1f} GB/s ({by/t_an/1e6/8000*100:5.1f}% of 8 TB/s) | "
+          f"synthesis(+gather) {t_sy*1e3:8.1f} us {by/t_sy/1e6:8.1f} GB/s | rfft_L {t_fft*1e3:8.1f} us")
