@@ -45,7 +45,9 @@ template <> struct AVec<4> {
 
 // Packed weights are permuted inside every BN-wide output-channel tile so that the NT values one lane feeds to
 // its NT MFMAs are contiguous in LDS: channel co0 + nt*32 + l  is stored at  co0 + l*NT + nt.
-template <int NT, int WP, int KC, int KW>
+// VEC = true: activations are staged as 16-byte loads / ds_write_b128 (needs T % 4 == 0 and 16-byte aligned rows);
+// the LDS row then carries its left halo at index 3 so that the body starts 16-byte aligned.
+template <int NT, int WP, int KC, int KW, bool VEC>
 __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_conv_args a, ConvGeom g) {
     constexpr int BN = NT * 32;
     constexpr int NPOS = 128 * WP;          // output positions per block
@@ -58,8 +60,11 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int PT = 1 << g.pt_log2;
     const int PR = 1 << g.pr_log2;
-    const int XROW = PT + 2;
-    const int XCH = PR * XROW;              // staged elements per channel (NPOS + 2*PR)
+    constexpr int padt = KW >> 1;
+    constexpr int XPAD = VEC ? 8 : 2;
+    constexpr int HOFF = VEC ? (4 - padt) : 0;   // LDS index of time t0 - padt within a row
+    const int XROW = PT + XPAD;
+    const int XCH = PR * XROW;              // staged elements per channel
     const int XBUF = (KC * XCH + 3) & ~3;
     const int BUF = XBUF + KW * KC * BN;    // floats per LDS buffer (double buffered)
 
@@ -101,11 +106,10 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
 #pragma unroll
     for (int wp = 0; wp < WP; ++wp) {
         const int p = (wave * WP + wp) * 32 + l31;
-        boff[wp] = (p >> g.pt_log2) * XROW + (p & (PT - 1)) + h * XCH;
+        boff[wp] = (p >> g.pt_log2) * XROW + (p & (PT - 1)) + HOFF + h * XCH;
     }
     const int aoff = XBUF + h * BN + l31 * NT;
 
-    constexpr int padt = KW >> 1;
     const int khc = a.KH >> 1;
     const int cin_split = a.in2 ? a.cin_split : a.Cin;
 
@@ -132,12 +136,79 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
     bool cok[CPT];         // channel < Cin
     bool okm[2];           // position inside the tensor
 
+    // ---- VEC staging slots: WP float4 body pieces + one halo scalar per thread
+    constexpr int NV = WP;                  // float4 pieces per thread (KC*NPOS/4/256)
+    f32x4 xv[NV];
+    float xh = 0.f;
+    float vsc[NV], hsc = 1.f;
+    bool vok[NV], hok = false;
+    int vlds[NV], vrow[NV], vci[NV], vt[NV];
+    const int q_per_row_log2 = g.pt_log2 - 2;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int idx = tid + v * 256;
+        const int q4 = idx & ((1 << q_per_row_log2) - 1);
+        const int r = (idx >> q_per_row_log2) & (PR - 1);
+        vci[v] = idx >> (g.pt_log2 + g.pr_log2 - 2);           // local channel 0..KC-1
+        vrow[v] = r;
+        vt[v] = t0 + 4 * q4;
+        vlds[v] = vci[v] * XCH + r * XROW + 4 + 4 * q4;
+    }
+    // halo: thread -> (channel, row, side)
+    const int hci = tid >> (g.pr_log2 + 1);
+    const int hrow = (tid >> 1) & (PR - 1);
+    const int hside = tid & 1;
+    const bool hactive = hci < KC && padt > 0;
+    const int ht = hside ? t0 + PT : t0 - 1;
+    const int hlds = hci * XCH + hrow * XROW + (hside ? PT + 4 : 3);
+
     auto kh_valid = [&](int kh) {
         const int foff = (kh - khc) * a.dil;
         return !(f0 + foff + PR <= 0 || f0 + foff >= a.F);
     };
+    auto chan_ptr = [&](int ci) {
+        return (ci < cin_split) ? a.in + (long)b * a.in_bs + (long)ci * a.in_cs
+                                : a.in2 + (long)b * a.in2_bs + (long)(ci - cin_split) * a.in2_cs;
+    };
+    auto load_x_vec = [&](int kh, int ci0) {
+        const int foff = (kh - khc) * a.dil;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int cir = ci0 + vci[v];
+            const int f = f0 + vrow[v] + foff;
+            const bool ok = cir < a.Cin && f >= 0 && f < a.F && vt[v] < a.T;
+            const int ci = cir < a.Cin ? cir : a.Cin - 1;
+            const float* src = chan_ptr(ci);
+            const long off = ok ? (long)f * a.T + vt[v] : 0;
+            xv[v] = *reinterpret_cast<const f32x4*>(src + off);
+            vsc[v] = a.in_scale ? a.in_scale[b * a.Cin + ci] : 1.f;
+            vok[v] = ok;
+        }
+        if (hactive) {
+            const int cir = ci0 + hci;
+            const int f = f0 + hrow + foff;
+            const bool ok = cir < a.Cin && f >= 0 && f < a.F && ht >= 0 && ht < a.T;
+            const int ci = cir < a.Cin ? cir : a.Cin - 1;
+            const float* src = chan_ptr(ci);
+            xh = src[ok ? (long)f * a.T + ht : 0];
+            hsc = a.in_scale ? a.in_scale[b * a.Cin + ci] : 1.f;
+            hok = ok;
+        }
+    };
+    auto store_x_vec = [&](float* buf) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (vok[v]) o = xv[v] * vsc[v];
+            *reinterpret_cast<f32x4*>(buf + vlds[v]) = o;
+        }
+        if (hactive) buf[hlds] = hok ? xh * hsc : 0.f;
+    };
     auto load_chunk = [&](int kh, int ci0) {
         const int foff = (kh - khc) * a.dil;
+        if constexpr (VEC) {
+            load_x_vec(kh, ci0);
+        } else {
         // wave-uniform per-channel base pointers and scales (scalar registers / scalar loads)
         const float* srcj[CPT];
 #pragma unroll
@@ -158,6 +229,7 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
 #pragma unroll
             for (int j = 0; j < CPT; ++j) xr[s2][j] = srcj[j][off];      // raw; masked + scaled at store time
         }
+        }
 #pragma unroll
         for (int jj = 0; jj < WJ; ++jj) {
             int idx = tid + jj * 256;
@@ -171,6 +243,9 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
         }
     };
     auto store_chunk = [&](float* buf) {
+        if constexpr (VEC) {
+            store_x_vec(buf);
+        } else {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
             if (sv[s2]) {
@@ -178,6 +253,7 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
                 for (int j = 0; j < CPT; ++j)
                     buf[(cgrp + j) * XCH + se[s2]] = (okm[s2] && cok[j]) ? xr[s2][j] * scj[j] : 0.f;
             }
+        }
 #pragma unroll
         for (int jj = 0; jj < WJ; ++jj) {
             const int idx = tid + jj * 256;
@@ -200,7 +276,8 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
             while (nkh < a.KH && !kh_valid(nkh)) ++nkh;
         }
         const bool has_next = nkh < a.KH;
-        if (has_next) load_chunk(nkh, nci);      // global loads stay in flight under the MFMAs below
+        const bool dbg_nostage = g.prio_mode & 4, dbg_nobar = g.prio_mode & 8;     // timing ablations only
+        if (has_next && !dbg_nostage) load_chunk(nkh, nci);      // global loads stay in flight under the MFMAs below
         const float* Xs = smem + cur * BUF;
         // operand registers are prefetched one k-pair ahead of the MFMAs that consume them
         float av[2][NT], bv[2][WP];
@@ -225,8 +302,8 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
                 for (int wp = 0; wp < WP; ++wp)
                     acc[nt][wp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][nt], bv[c][wp], acc[nt][wp], 0, 0, 0);
         }
-        if (has_next) store_chunk(smem + (cur ^ 1) * BUF);
-        __syncthreads();
+        if (has_next && !dbg_nostage) store_chunk(smem + (cur ^ 1) * BUF);
+        if (!dbg_nobar) __syncthreads();
         if (!has_next) break;
         kh = nkh;
         ci0 = nci;
@@ -299,7 +376,7 @@ inline int ilog2_ceil(int v) {
     return l;
 }
 
-template <int NT, int WP, int KW>
+template <int NT, int WP, int KW, bool VEC>
 int launch_conv(const babe_conv_args& a, ConvGeom g, hipStream_t s) {
     constexpr int KC = 8;
     constexpr int NPOS = 128 * WP;
@@ -312,8 +389,16 @@ int launch_conv(const babe_conv_args& a, ConvGeom g, hipStream_t s) {
     g.tiles_t = cdiv(a.T, PT);
     const int tiles_f = cdiv(a.F, PR);
     dim3 grid(g.tiles_t * tiles_f, g.CoutP / (NT * 32), a.B);
-    const size_t lds = 2 * ((size_t)((KC * PR * (PT + 2) + 3) & ~3) + (size_t)KW * KC * NT * 32) * sizeof(float);
-    hipLaunchKernelGGL((conv_mfma_kernel<NT, WP, KC, KW>), grid, dim3(256), lds, s, a, g);
+    size_t lds = 2 * ((size_t)((KC * PR * (PT + (VEC ? 8 : 2)) + 3) & ~3) + (size_t)KW * KC * NT * 32) * sizeof(float);
+    {   // occupancy cap (blocks per CU) by over-allocating LDS: BABE_CONV_OCC=n (experiment knob)
+        static const char* oc = getenv("BABE_CONV_OCC");
+        const int occ = oc ? atoi(oc) : 0;
+        if (occ > 0) {
+            const size_t need = (size_t)(160 * 1024) / (occ + 1) + 64;
+            if (lds < need) lds = need;
+        }
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<NT, WP, KC, KW, VEC>), grid, dim3(256), lds, s, a, g);
     return 0;
 }
 
@@ -436,9 +521,22 @@ extern "C" int babe_conv2d(const babe_conv_args* ap, void* stream) {
         bool on;
         ~ProfStop() { if (on) hipEventRecord(prof_event(), s); }
     } prof_stop{s, prof};
+    // vector staging needs 16-byte aligned rows in every source tensor
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    bool vec = (a.T % 4 == 0) && al16(a.in) && (a.in_bs % 4 == 0) && (a.in_cs % 4 == 0) &&
+               (!a.in2 || (al16(a.in2) && a.in2_bs % 4 == 0 && a.in2_cs % 4 == 0));
+    {
+        static const char* ov = getenv("BABE_CONV_VEC");
+        if (ov && ov[0] == '0') vec = false;
+    }
 #define BABE_CONV_CASE(NTv, WPv)                                          \
-    if (a.KW == 3) launch_conv<NTv, WPv, 3>(a, g, s);                     \
-    else launch_conv<NTv, WPv, 1>(a, g, s);
+    if (a.KW == 3) {                                                      \
+        if (vec) launch_conv<NTv, WPv, 3, true>(a, g, s);                 \
+        else launch_conv<NTv, WPv, 3, false>(a, g, s);                    \
+    } else {                                                              \
+        if (vec) launch_conv<NTv, WPv, 1, true>(a, g, s);                 \
+        else launch_conv<NTv, WPv, 1, false>(a, g, s);                    \
+    }
     if (wp2) {
         switch (NT) {
             case 4: BABE_CONV_CASE(4, 2) break;
