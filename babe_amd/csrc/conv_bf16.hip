@@ -17,6 +17,64 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+__device__ __forceinline__ float sel_scale(bool has, float loaded) { return has ? loaded : 1.f; }
+
+// Epilogue shared by all conv kernels: out = alpha*acc*oscale[b,co] + rbeta*res.  The 16 loads of a 32x32 tile are
+// issued back-to-back inside ONE wave-uniform branch per operand: a per-element "if (ptr) load" makes hipcc branch
+// around every load and wait vmcnt(0) each time (measured: the epilogue then serialises 128 load latencies).
+template <int NT, int WP, bool HAS_OS, bool HAS_RES>
+__device__ __forceinline__ void conv_epilogue_impl(const babe_conv_args& a, f32x16 (&acc)[NT][WP], int b, int co0,
+                                                   int f0, int t0, int pt_log2, int wave, int l31, int h) {
+    const int PT = 1 << pt_log2;
+#pragma unroll
+    for (int wp = 0; wp < WP; ++wp) {
+        const int p = (wave * WP + wp) * 32 + l31;
+        const int f = f0 + (p >> pt_log2);
+        const int t = t0 + (p & (PT - 1));
+        const bool pv = f < a.F && t < a.T;
+        const long sp = pv ? (long)f * a.T + t : 0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float os[16], rr[16];
+            int cc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                cc[r] = co < a.Cout ? co : a.Cout - 1;
+            }
+            if constexpr (HAS_OS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) os[r] = a.oscale[b * a.Cout + cc[r]];
+            }
+            if constexpr (HAS_RES) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rr[r] = a.res[(long)b * a.res_bs + (long)cc[r] * a.res_cs + sp];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = acc[nt][wp][r] * a.alpha;
+                if constexpr (HAS_OS) v *= os[r];
+                if constexpr (HAS_RES) v += a.rbeta * rr[r];
+                if (pv && co < a.Cout) a.out[(long)b * a.out_bs + (long)co * a.out_cs + sp] = v;
+            }
+        }
+    }
+}
+
+template <int NT, int WP>
+__device__ __forceinline__ void conv_epilogue(const babe_conv_args& a, f32x16 (&acc)[NT][WP], int b, int co0, int f0,
+                                              int t0, int pt_log2, int wave, int l31, int h) {
+    // four straight-line specialisations behind wave-uniform branches
+    if (a.oscale) {
+        if (a.res) conv_epilogue_impl<NT, WP, true, true>(a, acc, b, co0, f0, t0, pt_log2, wave, l31, h);
+        else conv_epilogue_impl<NT, WP, true, false>(a, acc, b, co0, f0, t0, pt_log2, wave, l31, h);
+    } else {
+        if (a.res) conv_epilogue_impl<NT, WP, false, true>(a, acc, b, co0, f0, t0, pt_log2, wave, l31, h);
+        else conv_epilogue_impl<NT, WP, false, false>(a, acc, b, co0, f0, t0, pt_log2, wave, l31, h);
+    }
+}
+
 struct ConvGeomB {
     int GP, CoutP, pt_log2, pr_log2, tiles_t;
     long split_stride;      // elements (shorts) between the hi and lo weight images
@@ -73,6 +131,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(babe_conv_args a, Con
     constexpr int padt = KW >> 1;
     const int khc = a.KH >> 1;
     const int cin_split = a.in2 ? a.cin_split : a.Cin;
+    const float* isc = a.in_scale ? a.in_scale : a.in;     // always-readable address: the load below is unconditional
+    const bool has_isc = a.in_scale != nullptr;
     const int CinP = g.GP * 8;
 
     const int pg = tid & (NPOS - 1);
@@ -111,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(babe_conv_args a, Con
             const int ci = cok[j] ? cir : a.Cin - 1;
             srcj[j] = (ci < cin_split) ? a.in + (long)b * a.in_bs + (long)ci * a.in_cs
                                        : a.in2 + (long)b * a.in2_bs + (long)(ci - cin_split) * a.in2_cs;
-            scj[j] = a.in_scale ? a.in_scale[b * a.Cin + ci] : 1.f;
+            scj[j] = sel_scale(has_isc, isc[b * a.Cin + ci]);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -209,27 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(babe_conv_args a, Con
         cur ^= 1;
     }
 
-#pragma unroll
-    for (int wp = 0; wp < WP; ++wp) {
-        const int p = (wave * WP + wp) * 32 + l31;
-        const int f = f0 + (p >> g.pt_log2);
-        const int t = t0 + (p & (PT - 1));
-        if (f >= a.F || t >= a.T) continue;
-        const long sp = (long)f * a.T + t;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co < a.Cout) {
-                    float v = acc[nt][wp][r] * a.alpha;
-                    if (a.oscale) v *= a.oscale[b * a.Cout + co];
-                    if (a.res) v += a.rbeta * a.res[(long)b * a.res_bs + (long)co * a.res_cs + sp];
-                    a.out[(long)b * a.out_bs + (long)co * a.out_cs + sp] = v;
-                }
-            }
-        }
-    }
+    conv_epilogue<NT, WP>(a, acc, b, co0, f0, t0, g.pt_log2, wave, l31, h);
 }
 
 // dst [s][kh][kw][g][coP][8]
