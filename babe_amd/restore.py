@@ -1,0 +1,52 @@
+"""Command line: blind bandwidth extension of one wav file on the MI355X path.
+
+    python -m babe_amd.restore in.wav out_dir [--ckpt weights.pt] [--precision f32|bf16x3|bf16] [--T 35]
+
+Follows the reference's file-level flow (testing/blind_bwe_tester.py:321-577 formal_test_bwe, blind mode):
+read -> (resample is NOT done here: the file must already be at exp.sample_rate) -> normalise to sigma_norm std
+-> segments + blind restoration + cross-fade (babe_amd/testing/long_file.py) -> write wav + filter pickle.
+Without --ckpt the network has random weights (useful only to exercise the path).
+"""
+import argparse
+import os
+
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("wav")
+    ap.add_argument("out_dir")
+    ap.add_argument("--ckpt")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--T", type=int, default=35)
+    ap.add_argument("--sample-rate", type=int, default=44100)
+    ap.add_argument("--audio-len", type=int, default=368368)
+    ap.add_argument("--batch", type=int, default=8, help="segments restored per batch")
+    ap.add_argument("--sigma-norm", type=float, default=0.1)
+    a = ap.parse_args()
+    from .config import default_args
+    from .diff_params.edm import EDM
+    from .io import load_checkpoint, read_audio_file, write_audio_file, write_filter_data
+    from .networks.cqtdiff_plus import Unet_CQT_oct_with_attention
+    from .testing.blind_bwe_sampler import BlindSampler
+    from .testing.long_file import restore_file
+    args = default_args(sample_rate=a.sample_rate, audio_len=a.audio_len, T=a.T)
+    net = Unet_CQT_oct_with_attention(args, "cuda", precision=a.precision)
+    if a.ckpt:
+        load_checkpoint(net, a.ckpt)
+    y, sr = read_audio_file(a.wav)
+    if sr != a.sample_rate:
+        raise SystemExit(f"{a.wav} is sampled at {sr} Hz; resample it to {a.sample_rate} Hz first")
+    std = float(y.std())
+    y = (y * (a.sigma_norm / std)).cuda()
+    sampler = BlindSampler(net, EDM(args), args, batch_semantics="per_clip")
+    out, filt = restore_file(sampler, y, batch_size=a.batch)
+    name = os.path.splitext(os.path.basename(a.wav))[0]
+    p = write_audio_file(out * (std / a.sigma_norm), sr, name, a.out_dir)
+    write_filter_data(filt, a.out_dir, name)
+    print(p)
+
+
+if __name__ == "__main__":
+    main()

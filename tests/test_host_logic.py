@@ -111,3 +111,21 @@ def test_long_file_segmentation_and_crossfade(L):
     segs = cut_segments(y, segL, plan)
     out = assemble(segs, plan, L, segL)
     assert torch.allclose(out, y, atol=1e-6)
+
+
+def test_checkpoint_conventions_and_wav_io(tmp_path):
+    from babe_amd.io import ema_state_dict, read_audio_file, write_audio_file, write_filter_data
+    model = {"a.weight": torch.ones(2, 2, requires_grad=True), "b.kernel": torch.zeros(3), "c.bias": torch.ones(2, requires_grad=True)}
+    ema = {"a.weight": torch.full((2, 2), 5.0), "b.kernel": torch.zeros(3), "c.bias": torch.full((2,), 7.0)}
+    assert torch.equal(ema_state_dict({"ema": ema, "it": 3})["a.weight"], ema["a.weight"])
+    sd2 = ema_state_dict({"model": model, "ema_weights": [ema[k] for k in model]})
+    assert all(torch.equal(sd2[k], ema[k]) for k in model)
+    sd3 = ema_state_dict({"model": model, "ema_weights": [ema["a.weight"], ema["c.bias"]]})
+    assert torch.equal(sd3["a.weight"], ema["a.weight"]) and torch.equal(sd3["c.bias"], ema["c.bias"]) and torch.equal(sd3["b.kernel"], model["b.kernel"])
+    x = 0.1 * torch.randn(5000)
+    p = write_audio_file(x, 44100, "t", str(tmp_path))
+    y, sr = read_audio_file(p)
+    assert sr == 44100 and torch.allclose(x, y)
+    fp = write_filter_data([((0, 10), torch.ones(2, 5))], str(tmp_path), "t")
+    import pickle
+    assert pickle.load(open(fp, "rb"))[0][0] == (0, 10)
