@@ -88,7 +88,32 @@ __global__ __launch_bounds__(256) void fir_same_kernel(const float* __restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void mask_blend_kernel(float* __restrict__ out, const float* __restrict__ mask,
+                                                         long mask_bs, const float* __restrict__ a,
+                                                         const float* __restrict__ b_, long n) {
+    const int b = blockIdx.y;
+    const float* m = mask + (long)b * mask_bs;
+    const long base = (long)b * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float mv = m[i];
+        float v = 0.f;
+        if (a) v += mv * a[base + i];
+        if (b_) v += (1.f - mv) * b_[base + i];
+        out[base + i] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int babe_mask_blend(float* out, const float* mask, long mask_bs, const float* a, const float* b_, int B,
+                               long n, void* stream) {
+    BABE_CHECK_ARG(out && mask && (a || b_) && B > 0 && n > 0, "mask_blend: bad arguments");
+    int bx = cdiv(n, 1024);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(mask_blend_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, out, mask, mask_bs, a, b_, n);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
 
 extern "C" int babe_fir_same(const float* x, long x_bs, const float* taps, int ntaps, float* out, long out_bs, int B,
                              int L, int adjoint, void* stream) {

@@ -43,6 +43,7 @@ def _register():
         "babe_sumsq_partial": [P, Lg, P, I, I, Lg, P],
         "babe_score_direction": [P, P, P, P, I, P, F, F, F, I, I, I, Lg, P],
         "babe_fir_same": [P, Lg, P, I, P, Lg, I, I, I, P],
+        "babe_mask_blend": [P, P, Lg, P, P, I, Lg, P],
     }
     for n, s in sig.items():
         fn = getattr(L, n)
@@ -67,6 +68,17 @@ def fir_same(x, taps, adjoint=False):
     taps = taps.reshape(-1).contiguous()
     check(lib().babe_fir_same(ptr(x), x.stride(0), ptr(taps), taps.numel(), ptr(out), out.stride(0), B, L,
                               int(adjoint), stream()), "fir_same")
+    return out
+
+
+def mask_blend(mask, a=None, b=None):
+    """mask*a + (1-mask)*b with a/b optional (None = 0); mask [L] (shared) or [B,L]."""
+    _register()
+    ref = a if a is not None else b
+    B, n = ref.shape
+    out = torch.empty_like(ref)
+    mbs = 0 if mask.dim() == 1 or mask.shape[0] == 1 else mask.stride(0)
+    check(lib().babe_mask_blend(ptr(out), ptr(mask.contiguous()), mbs, ptr(a), ptr(b), B, n, stream()), "mask_blend")
     return out
 
 

@@ -21,7 +21,7 @@ high-pass, UNet input-VJP).  All tensor work is C-ABI calls; the host only seque
 """
 import torch
 
-from ..stft import STFTOps, fir_same, lincomb, make_fit_cfg
+from ..stft import STFTOps, fir_same, lincomb, make_fit_cfg, mask_blend
 from .._lib import check, lib, ptr, stream
 
 
@@ -63,6 +63,8 @@ class BlindSampler:
                                     weighting=ps.freq_weighting_filter)
         self._stft = None
         self.fir_taps = None
+        self.ar_mask = None            # predict_bwe_AR: degradation(x) = mask*x + (1-mask)*A(x)
+        self.dc = None                 # (smooth_mask, y_smooth_masked) of the replacement data-consistency step
 
     def update_diff_params(self):
         dp, src = self.diff_params, self.args.tester.diff_params
@@ -116,7 +118,26 @@ class BlindSampler:
         B, L = x.shape
         x_den = self.get_denoised_estimate(x, t)
         cskip, cout, cin = self._c
-        if self.fir_taps is not None:
+        if self.ar_mask is not None:
+            # mask-mixed degradation of predict_bwe_AR (:280-288): mask*x + (1-mask)*A(x), A = fc_A filter or FIR
+            m = self.ar_mask
+            if self.fir_taps is not None:
+                rec0 = fir_same(x_den, self.fir_taps)
+            else:
+                H = st.design_filter(filter_params)
+                Hq = H if H.shape[0] == B else H[0]
+                rec0 = st.ola(st.filter_frames(st.stft(x_den), Hq), normalise=True)
+            rec = mask_blend(m, x_den, rec0)
+            r = lincomb(torch.empty_like(y), 1.0, y, -1.0, rec)
+            part = self._sumsq(r)
+            seed_raw = st.residual_seed(r, part, post=False)                 # -r/||r||
+            if self.fir_taps is not None:
+                gA = fir_same(mask_blend(m, None, seed_raw), self.fir_taps, adjoint=True)
+            else:
+                u = mask_blend(m, None, st.residual_seed(r, part, post=True))
+                gA = st.ola(st.filter_frames(st.stft(u), Hq), normalise=False)
+            g_den = lincomb(torch.empty_like(gA), 1.0, mask_blend(m, seed_raw, None), 1.0, gA)
+        elif self.fir_taps is not None:
             # known FIR degradation (edm_sampler.py:245-252): residual, then the transpose FIR
             rec = fir_same(x_den, self.fir_taps)
             r = lincomb(torch.empty_like(y), 1.0, y, -1.0, rec)
@@ -143,10 +164,17 @@ class BlindSampler:
                                          float(self.xi), float(self.args.exp.audio_len),
                                          int(self.batch_semantics == "reference"), self.SCORE_MODE, B, L, stream()),
               "score_direction")
+        if self.dc is not None:
+            # replacement data-consistency step (:63-73, :178-188): x0 <- y_sm + x0 - smooth_mask*x0 on the Tweedie
+            # estimate x0 = x + t^2*score = x - t*d, then back to a direction
+            sm, y_sm = self.dc
+            x0 = lincomb(torch.empty_like(x), 1.0, x, -float(t), d)
+            x0 = lincomb(torch.empty_like(x), 1.0, mask_blend(sm, None, x0), 1.0, y_sm)
+            d = lincomb(torch.empty_like(x), 1.0 / float(t), x, -1.0 / float(t), x0)
         return d, x_den, filter_params
 
     # ------------------------------------------------------------------ sampling loops
-    def _sample(self, y, filter_params, blind, rid):
+    def _sample(self, y, filter_params, blind, rid, snoise=1.0):
         dp = self.diff_params
         device = y.device
         y = y.contiguous().float()
@@ -169,7 +197,7 @@ class BlindSampler:
             # move_timestep (:509-516), Snoise = 1 as in predict_blind_bwe (:687)
             t_hat = t[i] + gamma[i] * t[i]
             eps = self._randn((B, L), device).contiguous()
-            x_hat = lincomb(torch.empty_like(x), 1.0, x, float((t_hat ** 2 - t[i] ** 2) ** (1 / 2)), eps)
+            x_hat = lincomb(torch.empty_like(x), 1.0, x, float((t_hat ** 2 - t[i] ** 2) ** (1 / 2)) * float(snoise), eps)
             d, x_den, filter_params = self.evaluate(x_hat, float(t_hat), y, specY, filter_params, blind)
             if rid:
                 data_denoised[i] = x_den.cpu()
@@ -210,4 +238,57 @@ class BlindSampler:
         if p.dim() == 1:
             p = p.unsqueeze(1)
         res = self._sample(ylpf, p.unsqueeze(0).contiguous().to(ylpf.device), blind=False, rid=rid)
+        return res if rid else res[0]
+
+    # ------------------------------------------------------------------ autoregressive out-painting ("next" row 2)
+    @staticmethod
+    def prepare_smooth_mask(mask, size=10):
+        """Hann-smoothed copy of a 0/1 mask [B,N] (:232-257): every 1->0 edge gets the falling half window just
+        before it, every 0->1 edge the rising half just after it.  Vectorised form of the reference's Python loop."""
+        hann = torch.hann_window(size * 2)
+        left, right = hann[0:size], hann[size:]
+        B, N = mask.shape
+        m = mask[0].detach().cpu()
+        new = m.clone()
+        prev = torch.cat((torch.ones(1), m[:-1]))
+        for i in torch.nonzero(m != prev).flatten().tolist():
+            if m[i] == 0:
+                new[i - size:i] = right
+            else:
+                new[i:i + size] = left
+        return new.unsqueeze(0).expand(B, -1).contiguous().to(mask.device)
+
+    def predict_bwe_AR(self, ylpf, y_masked, filt, filt_type, rid=False, test_filter_fit=False, compute_sweep=False,
+                       mask=None):
+        """(:259-303) observations = mask*y_masked + (1-mask)*ylpf; degradation(x) = mask*x + (1-mask)*A(x)."""
+        assert mask is not None
+        if test_filter_fit or compute_sweep:
+            raise NotImplementedError("test_filter_fit / compute_sweep (logging only)")
+        dev = ylpf.device
+        ylpf = ylpf.contiguous().float()
+        mask = mask.to(dev).float().contiguous()
+        y_masked = y_masked.to(dev).float().contiguous()
+        B, L = ylpf.shape
+        if filt_type == "fc_A":
+            p = torch.as_tensor(filt, dtype=torch.float32)
+            if p.dim() == 1:
+                p = p.unsqueeze(1)
+            params = p.unsqueeze(0).contiguous().to(dev)
+            self.fir_taps = None
+        elif filt_type == "firwin":
+            self.fir_taps = torch.as_tensor(filt, dtype=torch.float32).reshape(-1).contiguous().to(dev)
+            params = torch.zeros(1, 2, 1, device=dev)
+        else:
+            raise NotImplementedError(filt_type)
+        y = mask_blend(mask, y_masked, ylpf)
+        self.ar_mask = mask
+        self.dc = None
+        if self.args.tester.complete_recording.inpaint_DC:
+            sm = self.prepare_smooth_mask(mask, 50)
+            self.dc = (sm, mask_blend(sm, y_masked, None))
+            self.data_consistency = True                      # the reference flips this permanently (:300)
+        try:
+            res = self._sample(y, params, blind=False, rid=rid, snoise=self.diff_params.Snoise)
+        finally:
+            self.ar_mask, self.dc, self.fir_taps = None, None, None
         return res if rid else res[0]

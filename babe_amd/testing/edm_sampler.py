@@ -37,6 +37,8 @@ class Sampler(BlindSampler):
         self.noise_device = noise_device
         self._stft = None
         self.fir_taps = None
+        self.ar_mask = None
+        self.dc = None
 
     def stft_ops(self, L, device):
         if self._stft is None or self._stft.L != L:

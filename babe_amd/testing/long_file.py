@@ -75,3 +75,48 @@ def restore_file(sampler, y, batch_size=8, blind=True, filt=None):
     preds = torch.cat(preds, 0)
     out = assemble(preds, plan, L, segL, 200, ola)
     return out, [((s, s + segL), f) for (s, _), f in zip(plan, filters)]
+
+
+def restore_file_AR(sampler, y, filt, filt_type="fc_A", overlap_s=0.25, discard_end=200):
+    """Autoregressive out-painting of a whole recording with a KNOWN (previously estimated) filter, as the second
+    half of BlindTester.test_real_blind_bwe_complete does (/root/reference/testing/blind_bwe_tester.py:786-859):
+    the first segment is restored with predict_bwe, every following segment starts `overlap` samples inside the
+    previous result, which is passed as already-known signal (mask = 1 there) to predict_bwe_AR.  Sequential by
+    construction; y [L] device tensor -> restored [L]."""
+    segL = sampler.args.exp.audio_len
+    overlap = int(overlap_s * sampler.args.exp.sample_rate)
+    L = y.shape[-1]
+    dev = y.device
+    out = torch.zeros(L, device=dev)
+    if L <= segL:
+        seg = torch.zeros(1, segL, device=dev)
+        seg[0, :L] = y
+        return sampler.predict_bwe(seg, filt, filt_type)[0, :L]
+    ix = 0
+    pred = sampler.predict_bwe(y[ix:ix + segL].unsqueeze(0).contiguous(), filt, filt_type)
+    prev = pred[..., : segL - discard_end]
+    out[ix:ix + segL - discard_end] = prev[0]
+    ix += segL - overlap - discard_end
+    y_masked = torch.zeros(1, segL, device=dev)
+    mask = torch.ones(1, segL, device=dev)
+    mask[..., overlap:] = 0
+    while ix < L - segL - discard_end:
+        y_masked[..., :overlap] = prev[..., segL - overlap - discard_end:]
+        pred = sampler.predict_bwe_AR(y[ix:ix + segL].unsqueeze(0).contiguous(), y_masked, filt, filt_type, mask=mask)
+        prev = pred[..., : segL - discard_end]
+        out[ix:ix + segL - discard_end] = prev[0]
+        ix += segL - overlap - discard_end
+    seg = y[ix:]
+    n = seg.shape[-1]
+    y_masked[..., :overlap] = pred[..., -overlap:]           # (the reference takes the tail of the last prediction, :842)
+    if n < segL:
+        seg_zp = torch.zeros(1, segL, device=dev)
+        seg_zp[0, :n] = seg
+        y_masked[..., n:] = 0
+        mask[..., n:] = 0
+    else:
+        seg_zp = seg[:segL].unsqueeze(0).contiguous()
+        n = segL
+    pred = sampler.predict_bwe_AR(seg_zp, y_masked, filt, filt_type, mask=mask)
+    out[ix:ix + n] = pred[0, :n]
+    return out

@@ -171,6 +171,10 @@ int babe_fir_same(const float* x, long x_bs, const float* taps, int ntaps, float
 /* out = a*x + b*y + c*z (y, z optional) over n elements */
 int babe_lincomb3(float* out, float a, const float* x, float b, const float* y, float c, const float* z, long n,
                   void* stream);
+/* out[b][i] = m[i]*a[b][i] + (1-m[i])*b_[b][i]; a or b_ may be NULL (= 0); mask stride mask_bs (0: shared).
+ * Mask-mixed degradation and the replacement data-consistency step of predict_bwe_AR (blind_bwe_sampler.py:63-73,280-300) */
+int babe_mask_blend(float* out, const float* mask, long mask_bs, const float* a, const float* b_, int B, long n,
+                    void* stream);
 /* part[b][blk] = sum of squares of g[b][blk-th slice] (double) */
 int babe_sumsq_partial(const float* g, long g_bs, double* part, int nblk, int B, long n, void* stream);
 /* mode 0 (blind_bwe_sampler.py:125-135,701): d = -t*((xden-xhat)/t^2 - s*g/t), s = xi/(||g||/sqrt(audio_len) + 1e-6)

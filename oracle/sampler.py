@@ -120,3 +120,62 @@ class OracleEDMSampler:
             else:
                 x = x_hat + h * d
         return x.detach()
+
+
+def smooth_mask(mask, size):
+    """prepare_smooth_mask, /root/reference/testing/blind_bwe_sampler.py:232-257 (same element-by-element walk)."""
+    hann = torch.hann_window(size * 2)
+    left, right = hann[0:size], hann[size:]
+    B, N = mask.shape
+    m = mask[0]
+    prev = 1
+    new = m.clone()
+    for i in range(len(m)):
+        if m[i] != prev:
+            if m[i] == 0:
+                new[i - size:i] = right
+            if m[i] == 1:
+                new[i:i + size] = left
+        prev = m[i]
+    return new.unsqueeze(0).expand(B, -1)
+
+
+def predict_bwe_AR(smp, ylpf, y_masked, params, mask, noises, inpaint_DC=True):
+    """OracleBlindSampler + the AR degradation / data-consistency step: blind_bwe_sampler.py:259-303 ('fc_A'),
+    get_score :160-188, data_consistency_step_classic :63-73, predict :406-498."""
+    p = smp.p
+    y = mask * y_masked + (1 - mask) * ylpf
+    if inpaint_DC:
+        sm = smooth_mask(mask, 50)
+        y_sm = sm * y_masked
+    t = E.schedule(p, smp.T, smp.start_sigma)
+    it = iter(noises)
+    x = y + next(it) * t[0]
+    gam = E.gamma(p, t)
+
+    def score_fn(xx, tt):
+        xx = xx.detach().requires_grad_(True)
+        x_den = smp.denoised(xx, tt)
+        H = U.design_filter(params[0], params[1], smp.freqs)
+        rec = mask * x_den + (1 - mask) * U.apply_filter(x_den, H, smp.nfft)
+        norm = torch.linalg.norm(y - rec, dim=1, ord=2)
+        g, = torch.autograd.grad(norm.sum(), xx)
+        s = smp.xi / (torch.linalg.norm(g) / smp.audio_len ** 0.5 + 1e-6)
+        score = (x_den.detach() - xx.detach()) / tt ** 2 - s * g / tt
+        if inpaint_DC:
+            x0 = score * tt ** 2 + xx.detach()
+            x0 = y_sm + x0 - sm * x0
+            score = (x0 - xx.detach()) / tt ** 2
+        return score
+
+    for i in range(smp.T):
+        t_hat = t[i] + gam[i] * t[i]
+        x_hat = x + ((t_hat ** 2 - t[i] ** 2) ** 0.5) * (next(it) * p.Snoise)
+        d = -t_hat * score_fn(x_hat, t_hat)
+        h = t[i + 1] - t_hat
+        if t[i + 1] != 0 and smp.order == 2:
+            d2 = -t[i + 1] * score_fn(x_hat + h * d, t[i + 1])
+            x = x_hat + h * (0.5 * d + 0.5 * d2)
+        else:
+            x = x_hat + h * d
+    return x.detach()

@@ -349,7 +349,47 @@ def g9():
     save("edm_sampler_firwin.npz", **out)
 
 
+# ---------------------------------------------------------------- G10: AR out-painting (predict_bwe_AR)
+def g10():
+    args = small_args(T=3)
+    args.tester.posterior_sampling.start_sigma = 0.05
+    net, sd = build_ref_net(args)
+
+    class ResidualNet:
+        def __init__(self, inner, a, sigma_data):
+            self.inner, self.a, self.sd = inner, a, sigma_data
+            self.CQTransform = inner.CQTransform
+
+        def __call__(self, x, cnoise):
+            return self.a * self.inner(x, cnoise) + (torch.exp(4 * cnoise) / self.sd) * x
+
+    with quiet():
+        s = samp_mod.BlindSampler(ResidualNet(net, 0.3, 0.063), edm_mod.EDM(args), args)
+    L = args.exp.audio_len
+    g = torch.Generator().manual_seed(7007)
+    clean = 0.1 * torch.randn(1, L, generator=g)
+    f = torch.fft.rfftfreq(4096, d=1 / args.exp.sample_rate)
+    filt = torch.tensor([[2000.0], [-40.0]])
+    ylpf = bu.apply_filter(clean, bu.design_filter(filt[0], filt[1], f), 4096)
+    overlap = int(0.25 * args.exp.sample_rate)
+    mask = torch.ones(1, L)
+    mask[..., overlap:] = 0
+    y_masked = torch.zeros(1, L)
+    y_masked[..., :overlap] = clean[..., :overlap]
+    noises = [torch.randn(1, L, generator=g) for _ in range(1 + args.tester.T)]
+    it = iter(noises)
+    orig = torch.randn
+    torch.randn = lambda *a, **k: next(it)
+    try:
+        with quiet(), contextlib.redirect_stderr(io.StringIO()):
+            xr = s.predict_bwe_AR(ylpf.clone(), y_masked.clone(), filt, "fc_A", mask=mask)
+    finally:
+        torch.randn = orig
+    save("sampler_ar.npz", seed=7007, res_a=0.3, start_sigma=0.05, overlap=overlap, ylpf=ylpf, x=xr,
+         smooth_mask=s.prepare_smooth_mask(mask, 50)[0, : overlap + 8])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10"]
     for w in which:
         globals()[w]()

@@ -182,3 +182,28 @@ def test_blind_sampler_bf16x3_meets_fp32_parity_bar():
     smp._randn = lambda shape, device: next(it).to(device)
     x, fp = smp.predict_blind_bwe(s["y"].cuda())
     assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 5e-3
+
+
+def test_predict_bwe_AR_T3_vs_reference_golden():
+    """AR out-painting mode ("next" row 2): mask-mixed degradation + replacement data consistency."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    s = load("sampler_ar.npz")
+    g, args, net = small_net(T=3, start_sigma=float(s["start_sigma"]))
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    clean = 0.1 * torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    ov = int(s["overlap"])
+    mask = torch.ones(1, L)
+    mask[..., ov:] = 0
+    y_masked = torch.zeros(1, L)
+    y_masked[..., :ov] = clean[..., :ov]
+    smp = BlindSampler(ResidualNet(net, float(s["res_a"]), 0.063), EDM(args), args)
+    assert torch.equal(smp.prepare_smooth_mask(mask, 50)[0, : ov + 8], s["smooth_mask"])
+    it = iter(noises)
+    smp._randn = lambda shape, device: next(it).to(device)
+    x = smp.predict_bwe_AR(s["ylpf"].cuda(), y_masked.cuda(), torch.tensor([[2000.0], [-40.0]]), "fc_A", mask=mask.cuda())
+    assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 2e-3
+    # the observed (masked) region is reproduced by the data-consistency step
+    assert float((x[:, : ov - 60].cpu() - clean[:, : ov - 60]).abs().max()) < 5e-2

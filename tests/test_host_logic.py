@@ -129,3 +129,36 @@ def test_checkpoint_conventions_and_wav_io(tmp_path):
     fp = write_filter_data([((0, 10), torch.ones(2, 5))], str(tmp_path), "t")
     import pickle
     assert pickle.load(open(fp, "rb"))[0][0] == (0, 10)
+
+
+def test_long_file_AR_driver_sequence():
+    """Segment bookkeeping of the AR driver with a stand-in sampler that records what it is asked to do."""
+    from babe_amd.config import default_args
+    from babe_amd.testing.long_file import restore_file_AR
+
+    class Fake:
+        def __init__(self):
+            self.args = default_args(sample_rate=1000, audio_len=4000)
+            self.calls = []
+
+        def predict_bwe(self, seg, filt, filt_type):
+            self.calls.append(("bwe", seg.shape))
+            return seg.clone()
+
+        def predict_bwe_AR(self, seg, y_masked, filt, filt_type, mask=None):
+            self.calls.append(("ar", int(mask.sum())))
+            return mask * y_masked + (1 - mask) * seg
+
+    f = Fake()
+    y = torch.arange(11000, dtype=torch.float32)
+    out = restore_file_AR(f, y, None)
+    # identity "restoration": every sample is reproduced (known overlap regions carry the previous result) ...
+    hop = 4000 - 250 - 200
+    last = 2 * hop
+    assert torch.equal(out[:last], y[:last]) and torch.equal(out[last + 250:], y[last + 250:])
+    # ... except the known region of the LAST segment, which the reference fills from the tail of the previous
+    # prediction (pred[-overlap:], blind_bwe_tester.py:842) - 200 samples (discard_end) later than where that
+    # segment starts.  Reproduced as is.
+    assert torch.equal(out[last:last + 250], y[last + 200:last + 450])
+    assert f.calls[0][0] == "bwe" and all(c[0] == "ar" for c in f.calls[1:]) and len(f.calls) >= 3
+    assert f.calls[1][1] == 250                      # 0.25 s overlap at 1 kHz is the known region

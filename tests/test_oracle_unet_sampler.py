@@ -106,3 +106,31 @@ def test_fir_taps_and_apply():
     for k in range(500):                                   # out[n] = sum_k taps[k] x[n+k-249]
         y += taps[k] * xp[:, k:k + 5000]
     assert rel(y, s["fir_y"]) < 1e-5
+
+
+def _ar_inputs(s, L=92092):
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    clean = 0.1 * torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    ov = int(s["overlap"])
+    mask = torch.ones(1, L)
+    mask[..., ov:] = 0
+    y_masked = torch.zeros(1, L)
+    y_masked[..., :ov] = clean[..., :ov]
+    return noises, mask, y_masked
+
+
+def test_predict_bwe_AR_T3():
+    """AR out-painting (mask-mixed degradation + replacement data consistency) vs the reference (G10)."""
+    from oracle.sampler import predict_bwe_AR, smooth_mask
+    g, sd, cqt = small_net()
+    s = load("sampler_ar.npz")
+    L = 92092
+    noises, mask, y_masked = _ar_inputs(s)
+    assert torch.equal(smooth_mask(mask, 50)[0, : int(s["overlap"]) + 8], s["smooth_mask"])
+    a = float(s["res_a"])
+    p = E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10, Stmin=0, Stmax=50, Snoise=1.0)
+    net = lambda x, cn: a * UN.unet_forward(sd, CFG, cqt, x, cn) + (torch.exp(4 * cn) / 0.063) * x
+    smp = OracleBlindSampler(net, cqt, p, fs=22050, audio_len=L, T=3, start_sigma=float(s["start_sigma"]))
+    x = predict_bwe_AR(smp, s["ylpf"], y_masked, torch.tensor([[2000.0], [-40.0]]), mask, noises)
+    assert rel(x, s["x"]) < 1e-3
