@@ -207,3 +207,32 @@ def test_predict_bwe_AR_T3_vs_reference_golden():
     assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 2e-3
     # the observed (masked) region is reproduced by the data-consistency step
     assert float((x[:, : ov - 60].cpu() - clean[:, : ov - 60]).abs().max()) < 5e-2
+
+
+@pytest.mark.parametrize("fs,L,B", [(16000, 184184, 1), (22050, 92092, 3)])
+def test_unet_other_geometries_vs_oracle(fs, L, B):
+    """Config-#5 geometry (16 kHz CocoChorales, audio_len 184184: T_j = 32..2048) and an odd batch size:
+    HIP UNet forward + input-VJP vs the CPU oracle with autograd (reduced width)."""
+    from babe_amd.config import default_args
+    from babe_amd.networks.cqtdiff_plus import Unet_CQT_oct_with_attention
+    from oracle import unet as UN
+    from oracle.nsgt import CQT_nsgt as OracleCQT
+    g = load("unet_small.npz")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    args = default_args(sample_rate=fs, audio_len=L, Ns=[8, 8, 8, 8, 16, 16, 16])
+    net = Unet_CQT_oct_with_attention(args, "cuda")
+    net.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(L + B)
+    x = 0.1 * torch.randn(B, L, generator=gen)
+    cn = torch.full((B, 1), -0.3)
+    wv = torch.randn(B, L, generator=gen)
+    cfg = dict(num_octs=7, bins_per_oct=64, num_dils=[2, 3, 4, 5, 6, 7, 7])
+    ocqt = OracleCQT(7, 64, "oct", ("kaiser", 1), fs, L)
+    xr = x.clone().requires_grad_(True)
+    yref = UN.unet_forward(sd, cfg, ocqt, xr, cn)
+    gref, = torch.autograd.grad((yref * wv).sum(), xr)
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg, cn.cuda())
+    gx, = torch.autograd.grad((y * wv.cuda()).sum(), xg)
+    assert rel(y, yref) < 5e-5
+    assert rel(gx, gref) < 5e-4
