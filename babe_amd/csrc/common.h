@@ -32,6 +32,33 @@ void babe_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Channel addressing of the (optionally two-source) conv input with bases and strides pinned in scalar registers.
+// Written as a per-lane select between kernarg fields (ci < split ? a.in_cs : a.in2_cs) the compiler emits a
+// dependent global load of the selected field plus s_waitcnt vmcnt(0) in every K-chunk, draining the prefetch queue.
+__device__ __forceinline__ long sgpr_pin(long v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+struct ChanSrc {
+    const float* p1;      // batch-b base of the first source (stays a kernarg-derived global pointer)
+    long d2, cs1, cs2;    // second source as an element offset from p1; channel strides
+    int split;
+    __device__ __forceinline__ void init(const float* in, long bs, long cs, const float* in2, long bs2, long cs2_,
+                                         int split_, int b) {
+        p1 = in + (long)b * bs;
+        d2 = sgpr_pin(in2 ? (long)((in2 + (long)b * bs2) - p1) : 0);
+        cs1 = sgpr_pin(cs);
+        cs2 = sgpr_pin(in2 ? cs2_ : cs);
+        split = split_;
+    }
+    __device__ __forceinline__ const float* operator()(int ci) const {
+        const bool first = ci < split;
+        const long cs = first ? cs1 : cs2;
+        const int c = first ? ci : ci - split;
+        return p1 + ((first ? 0 : d2) + (long)c * cs);
+    }
+};
+
 // wave64 all-lane sum via DPP-free shuffles
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -226,10 +226,8 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
         const int foff = (kh - khc) * a.dil;
         return !(f0 + foff + PR <= 0 || f0 + foff >= a.F);
     };
-    auto chan_ptr = [&](int ci) {
-        return (ci < cin_split) ? a.in + (long)b * a.in_bs + (long)ci * a.in_cs
-                                : a.in2 + (long)b * a.in2_bs + (long)(ci - cin_split) * a.in2_cs;
-    };
+    ChanSrc chan_ptr;
+    chan_ptr.init(a.in, a.in_bs, a.in_cs, a.in2, a.in2_bs, a.in2_cs, cin_split, b);
     auto load_x_vec = [&](int kh, int ci0) {
         const int foff = (kh - khc) * a.dil;
 #pragma unroll
@@ -276,8 +274,7 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
             const int cir = ci0 + cgrp + j;
             cok[j] = cir < a.Cin;
             const int ci = cok[j] ? cir : a.Cin - 1;          // padded channels read a valid address
-            srcj[j] = (ci < cin_split) ? a.in + (long)b * a.in_bs + (long)ci * a.in_cs
-                                       : a.in2 + (long)b * a.in2_bs + (long)(ci - cin_split) * a.in2_cs;
+            srcj[j] = chan_ptr(ci);
             scj[j] = sel_scale(has_isc, isc[b * a.Cin + ci]);
         }
 #pragma unroll

@@ -157,6 +157,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(babe_conv_args a, Con
     bool cok[CPT];
     bool okm[2];
 
+    ChanSrc chan_ptr;
+    chan_ptr.init(a.in, a.in_bs, a.in_cs, a.in2, a.in2_bs, a.in2_cs, cin_split, b);
     auto kh_valid = [&](int kh) {
         const int foff = (kh - khc) * a.dil;
         return !(f0 + foff + PR <= 0 || f0 + foff >= a.F);
@@ -169,8 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(babe_conv_args a, Con
             const int cir = ci0 + cgrp + j;
             cok[j] = cir < a.Cin;
             const int ci = cok[j] ? cir : a.Cin - 1;
-            srcj[j] = (ci < cin_split) ? a.in + (long)b * a.in_bs + (long)ci * a.in_cs
-                                       : a.in2 + (long)b * a.in2_bs + (long)(ci - cin_split) * a.in2_cs;
+            srcj[j] = chan_ptr(ci);
             scj[j] = sel_scale(has_isc, isc[b * a.Cin + ci]);
         }
 #pragma unroll

@@ -1,6 +1,7 @@
 """Python views of the babe_hip C-ABI ops (UNet building blocks).  Device tensors only."""
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -18,6 +19,7 @@ def _view(t):
 
 
 PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
+WINOGRAD = os.environ.get("BABE_CONV_WINO", "1") != "0"      # debug switch: 0 forces the direct fp32 kernel
 
 
 class PackedConv:
@@ -56,6 +58,13 @@ class PackedConv:
         self.bwd = torch.empty(nb, device=w.device, dtype=torch.float32)
         check(L.babe_conv_pack_weights(ptr(w), ptr(self.fwd), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack")
         check(L.babe_conv_pack_weights(ptr(w), ptr(self.bwd), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack")
+        # Winograd F(2,3)-along-time images for the 3-tap kernels (used whenever the problem qualifies)
+        self.fwd_wino = self.bwd_wino = None
+        if self.KW == 3 and WINOGRAD:
+            self.fwd_wino = torch.empty(L.babe_conv_packed_size_wino(self.Cout, self.Cin, self.KH, 0), device=w.device)
+            self.bwd_wino = torch.empty(L.babe_conv_packed_size_wino(self.Cout, self.Cin, self.KH, 1), device=w.device)
+            check(L.babe_conv_pack_weights_wino(ptr(w), ptr(self.fwd_wino), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack_wino")
+            check(L.babe_conv_pack_weights_wino(ptr(w), ptr(self.bwd_wino), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino")
 
 
 def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=None, oscale=None, alpha=1.0, rbeta=0.0):
@@ -92,6 +101,8 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
     a.KH, a.KW, a.dil = pc.KH, pc.KW, dil
     if pc.splits:
         check(lib().babe_conv2d_bf16(C.byref(a), ptr(wq), pc.splits, stream()), "conv2d_bf16")
+    elif getattr(pc, "fwd_wino", None) is not None and lib().babe_conv2d_wino_supported(C.byref(a)):
+        check(lib().babe_conv2d_wino(C.byref(a), ptr(pc.bwd_wino if transpose else pc.fwd_wino), stream()), "conv2d_wino")
     else:
         check(lib().babe_conv2d(C.byref(a), stream()), "conv2d")
     return out

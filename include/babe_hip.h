@@ -48,6 +48,14 @@ int babe_conv2d_bf16(const babe_conv_args* a, const void* w_bf16, int splits, vo
 int babe_conv_pack_weights_bf16(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
                                 int splits, void* stream);
 long babe_conv_packed_size_bf16(int Cout, int Cin, int KH, int KW, int transpose_flip, int splits);
+/* Winograd F(2,3)-along-time variant of the exact-fp32 conv for KW == 3 (csrc/conv_wino.hip): 2/3 of the MFMA work,
+ * same result up to fp32 rounding.  w_wino from babe_conv_pack_weights_wino: [KH][ceil8(Cin)][ceil32(Cout)][4].
+ * babe_conv2d_wino_supported() tells whether a problem qualifies (even T, aligned rows, tileable Cout). */
+int babe_conv2d_wino(const babe_conv_args* a, const float* w_wino, void* stream);
+int babe_conv2d_wino_supported(const babe_conv_args* a);
+int babe_conv_pack_weights_wino(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
+                                void* stream);
+long babe_conv_packed_size_wino(int Cout, int Cin, int KH, int transpose_flip);
 /* Measurement hook (bench.py): when enabled every babe_conv2d launch is bracketed by HIP events on its
  * stream; read returns the summed kernel time, the summed ALGORITHMIC flops (2*B*Cout*Cin*KH*KW*F*T with the
  * unpadded channel counts) and the launch count, then resets. */

@@ -112,6 +112,71 @@ def test_conv2d_two_sources_and_views(ops):
     assert rel(out, UN.conv_same(xin[:, :, 64:, :].double(), w.double())) < 2e-6
 
 
+@pytest.mark.parametrize("B,C1,C2,Cout,Fq,T,dil", [
+    (2, 32, 32, 64, 48, 64, 2),       # two sources, 64co x 256pos variant
+    (1, 96, 0, 96, 40, 36, 4),        # 96 channels, T % 8 != 0
+    (1, 128, 128, 128, 33, 128, 16),  # 128co x 128pos variant, ragged F
+    (2, 5, 0, 20, 17, 20, 1),         # channel padding on both sides
+])
+def test_conv2d_winograd_vs_direct_and_oracle(ops, B, C1, C2, Cout, Fq, T, dil):
+    """Winograd F(2,3)-along-time kernel (csrc/conv_wino.hip) against the direct kernel and the float64 oracle."""
+    import ctypes as C
+    from babe_amd._lib import lib
+    g = torch.Generator().manual_seed(C1 + Cout + T)
+    Cin = C1 + C2
+    x = torch.randn(B, Cin, Fq, T, generator=g)
+    w = torch.randn(Cout, Cin, 5, 3, generator=g) / math.sqrt(Cin * 15)
+    res = torch.randn(B, Cout, Fq, T, generator=g)
+    osc = torch.randn(B, Cout, generator=g)
+    ref = 0.7 * UN.conv_same(x.double(), w.double(), dil) * osc[:, :, None, None].double() + 0.3 * res.double()
+    pcw = ops.PackedConv(w.cuda())
+    assert pcw.fwd_wino is not None
+    pcd = ops.PackedConv(w.cuda())
+    pcd.fwd_wino = pcd.bwd_wino = None
+    xc = x.cuda()
+    x1, x2 = (xc[:, :C1].contiguous(), xc[:, C1:].contiguous()) if C2 else (xc, None)
+    outs = []
+    for pc in (pcw, pcd):
+        big = torch.zeros(B, Cout, 2 * Fq, T, device="cuda")
+        o = big[:, :, Fq:, :]
+        o.copy_(res.cuda())
+        ops.conv2d(x1, pc, o, dil=dil, x2=x2, res=o, oscale=osc.cuda(), alpha=0.7, rbeta=0.3)
+        assert float(big[:, :, :Fq, :].abs().max()) == 0.0
+        outs.append(o.clone())
+    assert rel(outs[0], ref) < 2e-6 and rel(outs[1], ref) < 2e-6
+    assert rel(outs[0], outs[1]) < 2e-6
+    # input-VJP weights
+    gy = torch.randn(B, Cout, Fq, T, generator=g).cuda()
+    gx = [torch.empty(B, Cin, Fq, T, device="cuda") for _ in range(2)]
+    ops.conv2d(gy, pcw, gx[0], dil=dil, transpose=True)
+    ops.conv2d(gy, pcd, gx[1], dil=dil, transpose=True)
+    xr = x.double().requires_grad_(True)
+    gref, = torch.autograd.grad((UN.conv_same(xr, w.double(), dil) * gy.cpu().double()).sum(), xr)
+    assert rel(gx[0], gref) < 2e-6 and rel(gx[0], gx[1]) < 2e-6
+
+
+def test_conv2d_winograd_dispatch_rules(ops):
+    """Problems the Winograd kernel does not take (T % 4, misaligned views, 1x1) run on the direct kernel."""
+    import ctypes as C
+    from babe_amd._lib import ConvArgs, lib
+    w = torch.randn(32, 32, 5, 3, device="cuda") / 20
+    pc = ops.PackedConv(w)
+    for T in (30, 18):
+        x = torch.randn(1, 32, 16, T, device="cuda")
+        out = torch.empty(1, 32, 16, T, device="cuda")
+        ops.conv2d(x, pc, out, dil=2)
+        assert rel(out, UN.conv_same(x.cpu().double(), w.cpu().double(), 2)) < 2e-6
+    a = ConvArgs()
+    a.KW, a.KH, a.T, a.Cout = 3, 5, 30, 32
+    assert lib().babe_conv2d_wino_supported(C.byref(a)) == 0
+    a.T, a.KW = 32, 1
+    assert lib().babe_conv2d_wino_supported(C.byref(a)) == 0
+    a.KW = 3
+    assert lib().babe_conv2d_wino_supported(C.byref(a)) == 1
+    a.in_ = 4       # 4-byte aligned but not 16
+    assert lib().babe_conv2d_wino_supported(C.byref(a)) == 0
+
+
 @pytest.mark.parametrize("B,C,Fq,T", [(2, 16, 64, 24), (1, 64, 128, 256), (1, 8, 5, 8)])
 def test_groupnorm_film_gelu_fwd_bwd(ops, B, C, Fq, T):
     g = torch.Generator().manual_seed(C + T)
