@@ -89,6 +89,18 @@ def cpu_baseline(threads):
                       f"full-width network, {dt:.1f} s on {threads} threads, extrapolated x69"}
 
 
+def conv_traffic(precision):
+    """HBM-side bytes per conv launch from the committed PMC passes (rocprofv3 cannot run inside the bench):
+    profiles/r01_conv_traffic.json, FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE averaged over the same launches."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_traffic.json")
+    if precision != "f32" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    return {"bytes_per_launch": round(t["bytes_per_launch"]), "fetch": round(t["fetch_bytes_per_launch"]),
+            "write": round(t["write_bytes_per_launch"]), "source": "profiles/r01_conv_traffic.json (PMC passes, not live)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,14 +209,16 @@ def main():
         dtype = {"f32": "f32", "bf16x3": "bf16x3 (bf16 MFMA on hi/lo-split operands, fp32 storage+accumulate)",
                  "bf16": "bf16 (bf16 MFMA, fp32 storage+accumulate)"}[a.precision]
         peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "f32" else 2500.0
-        kname = ("conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM dilated conv, fwd + input-VJP)"
+        kname = ("babe_conv2d launches of the UNet: conv_wino_kernel / conv_wino_pp_kernel (Winograd F(2,3)-along-time, "
+                 "fp32 v_mfma_f32_32x32x2_f32) for the (5,3) layers, conv_mfma_kernel for (1,1); fwd + input-VJP; "
+                 "achieved counts the ALGORITHMIC (direct-convolution) flops"
                  if a.precision == "f32" else
                  "conv_bf16_kernel (v_mfma_f32_32x32x16_bf16; %s products per k-block; achieved counts ALGORITHMIC flops)"
                  % ("3" if a.precision == "bf16x3" else "1"))
         if a.profile_convs and ms.value > 0:
             ach = fl.value / (ms.value * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": conv_traffic(a.precision),
                     "kernel": kname,
                     "launches": nl.value, "avg_launch_us": round(ms.value * 1e3 / max(nl.value, 1), 2),
                     "algorithmic_tflop_per_launch_avg": round(fl.value / max(nl.value, 1) / 1e12, 5),
