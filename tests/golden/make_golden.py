@@ -389,7 +389,67 @@ def g10():
          smooth_mask=s.prepare_smooth_mask(mask, 50)[0, : overlap + 8])
 
 
+# ---------------------------------------------------------------- G11: denoiser pre-pass ("next" row 3)
+DN_CFGS = {
+    # conf/tester/blind_bwe_denoise_brass.yaml:157-176 (the shipped configuration), short input
+    "full": dict(depth=6, num_tfc=3, num_stages=2, use_SAM=True, use_fencoding=True, f_dim=513, T=48),
+    # reduced variants: single stage / no frequency encoding / no SAM
+    "s1": dict(depth=3, num_tfc=2, num_stages=1, use_SAM=False, use_fencoding=False, f_dim=129, T=40),
+    "nosam": dict(depth=2, num_tfc=1, num_stages=2, use_SAM=False, use_fencoding=True, f_dim=65, T=21),
+}
+
+
+def g11():
+    import types
+    for name in ("wandb", "omegaconf", "soundfile"):
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    dn = importlib.import_module("networks.denoiser")
+    tester = importlib.import_module("testing.denoise_and_bwe_tester")
+    from oracle import denoiser as OD
+    out = {}
+    for name, c in DN_CFGS.items():
+        ua = ref_shim.to_attr(dict(c))
+        net = dn.MultiStage_denoise(unet_args=ua)
+        sd = OD.init_state_dict(c, seed=7)
+        ref_sd = net.state_dict()
+        assert list(ref_sd.keys()) == list(sd.keys()), "state_dict names/order differ from the reference"
+        assert all(tuple(ref_sd[k].shape) == tuple(sd[k].shape) for k in sd)
+        if c["use_fencoding"]:
+            assert torch.equal(ref_sd["freq_encoding.fembeddings"], sd["freq_encoding.fembeddings"])
+        net.load_state_dict(sd)
+        g = torch.Generator().manual_seed(300 + len(name))
+        X = torch.randn(1 if name == "full" else 2, 2, c["T"], c["f_dim"], generator=g)
+        with torch.no_grad():
+            y = net(X)
+        out[f"{name}_seed"] = 300 + len(name)
+        if c["num_stages"] > 1:
+            out[f"{name}_pred2"], out[f"{name}_pred1"] = y
+        else:
+            out[f"{name}_pred1"] = y
+    # segmented application (denoise_and_bwe_tester.py:109-165) through the reference's own methods
+    c = dict(depth=3, num_tfc=1, num_stages=2, use_SAM=True, use_fencoding=True, f_dim=513)
+    net = dn.MultiStage_denoise(unet_args=ref_shim.to_attr(dict(c)))
+    net.load_state_dict(OD.init_state_dict(c, seed=11))
+    fake = types.SimpleNamespace()
+    fake.args = ref_shim.to_attr(dict(tester=dict(denoiser=dict(sample_rate_denoiser=4000, segment_size=2, stft_win_size=1024,
+                                                                stft_hop_size=256, num_stages=2))))
+    fake.device = torch.device("cpu")
+    fake.denoiser = net
+    fake.apply_denoiser_model = lambda seg: tester.BlindTester.apply_denoiser_model(fake, seg)
+    g = torch.Generator().manual_seed(411)
+    x = 0.1 * torch.randn(2, 20000, generator=g)
+    with torch.no_grad():
+        out["seg_model"] = tester.BlindTester.apply_denoiser_model(fake, x[:, :8000])
+        out["seg_full"] = tester.BlindTester.apply_denoiser(fake, x)
+    out["seg_seed"] = 411
+    save("denoiser.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()
