@@ -192,6 +192,42 @@ int babe_score_direction(const float* xden, const float* xhat, const float* g, c
                          float* d, float t, float xi, float audio_len, int shared_norm, int mode, int B, long n,
                          void* stream);
 
+/* ---- Denoiser pre-pass: networks/denoiser.py:232-321 (MultiStage_denoise, inference only) and
+ * testing/denoise_and_bwe_tester.py:146-165 (STFT 1024/256 -> network -> inverse STFT).  csrc/denoiser.hip --------- */
+/* General small-kernel Conv2d on [B][C][H][W] tensors with contiguous rows (replaces nn.Conv2d with
+ * padding_mode='reflect' denoiser.py:40-46, the 4x4 stride-2 down conv :358-363 and, as four 2x2 parity kernels, the
+ * ConvTranspose2d :383-388):  v = conv(in)[co][oh][ow] + bias[co];  act=1: v = ELU(v);  res: v += res[...];
+ * out[b][co][oh*out_hstep + out_h0][ow*out_wstep + out_w0] = v  where that index lies inside [out_H][out_W]
+ * (res is indexed like out).  Input index = o*stride - pad + k, reflected (pad_mode 1) or zero (0) outside. */
+typedef struct {
+    const float* in; long in_bs, in_cs; int IH, IW;
+    const float* bias;           /* [Cout] or NULL */
+    float* out; long out_bs, out_cs; int out_H, out_W, out_hstep, out_h0, out_wstep, out_w0;
+    const float* res; long res_bs, res_cs;
+    int B, Cin, Cout, OH, OW, KH, KW, stride, pad_t, pad_l, pad_mode, act;
+} babe_dnconv_args;
+int babe_dn_conv2d(const babe_dnconv_args* a, const float* w_packed, void* stream);
+/* mode 0: w [Cout][Cin][KH][KW] -> [KH][KW][ceil8(Cin)][ceil64(Cout)].  mode 1 (KH=KW=2): parity (ph,pw) of a
+ * ConvTranspose2d weight [Cin][Cout][4][4] with stride 2: out[2m+p] = sum_a in[m-a] w[p+2a]. */
+int babe_dn_pack_weights(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int mode, int ph, int pw,
+                         void* stream);
+long babe_dn_packed_size(int Cout, int Cin, int KH, int KW);
+/* out[b][c][h][w] += low[b][c][(h+dh)>>1][(w+dw)>>1]: nn.Upsample(2,'nearest') + CropAdd/CropConcat, denoiser.py:400-407 */
+int babe_dn_upsample_add(float* out, long out_bs, long out_cs, const float* low, long low_bs, long low_cs, int B, int C,
+                         int H, int W, int LH, int LW, int dh, int dw, void* stream);
+/* out = x1 * sigmoid(m) + feats (SAM, denoiser.py:126-130); x1, m contiguous [B][C][hw] */
+int babe_dn_sam_gate(const float* x1, const float* m, const float* feats, long f_bs, long f_cs, float* out, long out_bs,
+                     long out_cs, int B, int C, long hw, void* stream);
+/* out[B][2+nemb][T][F] = cat(X[B][2][T][F], femb[F][nemb] broadcast over b, t)  (AddFreqEncoding :159-169) */
+int babe_dn_fill_input(const float* X, const float* femb, float* out, int B, int T, int F, int nemb, void* stream);
+/* torch.stft(x, nfft, hop, hamming_window(nfft), center=False) as X[B][2][frames][nfft/2+1]; frames = 1+(L-nfft)/hop */
+int babe_dn_stft(const float* x, long x_bs, int L, float* X, int B, int nfft, int hop, int frames, const float* tw4096,
+                 void* stream);
+/* torch.istft(P, nfft, hop, hamming_window(nfft), center=False)[..., :Lout]; frames_ws: [B][frames][nfft] scratch */
+int babe_dn_istft(const float* P, float* frames_ws, float* y, long y_bs, int Lout, int B, int nfft, int hop, int frames,
+                  const float* tw4096, void* stream);
+
+
 #ifdef __cplusplus
 }
 #endif
