@@ -18,23 +18,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int DN_BN = 64, DN_TH = 4, DN_TW = 64, DN_KC = 8;
+constexpr int DN_BN = 64, DN_TH = 4, DN_TW = 64;
 
+// KH x KW kernel, stride S; a step = (KC input channels) x (KHC kernel rows): LDS holds the input rows those kernel
+// rows touch, [KC][(TH-1)*S+KHC][(TW-1)*S+KW], and the weight slab [KHC][KW][KC][64].  The next step's global loads are
+// issued (all of a thread's loads back to back, fully unrolled) before the MFMAs of the current step and written to LDS
+// after them, so their latency hides behind the matrix work.
+template <int KH, int KW, int S, int KHC, int KC>
 __global__ __launch_bounds__(256, 2) void dn_conv_kernel(babe_dnconv_args a, const float* __restrict__ wq, int CinP,
-                                                         int CoutP, int tiles_w, int PH, int PW, int KHC) {
+                                                         int CoutP, int tiles_w) {
+    constexpr int PH = (DN_TH - 1) * S + KHC, PW = (DN_TW - 1) * S + KW;
+    constexpr int NX = KC * PH * PW;                         // patch floats
+    constexpr int XJ = (NX + 255) / 256;
+    constexpr int NW4 = KHC * KW * KC * (DN_BN / 4);         // weight float4 per slab
+    constexpr int WJ = (NW4 + 255) / 256;
+    constexpr int NKG = (KH + KHC - 1) / KHC;                // kernel-row groups
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                              // [8][PH][PW]
-    float* Ws = smem + DN_KC * PH * PW;            // [KHC][KW][8][64]
+    float* Xs = smem;
+    float* Ws = smem + (NX + 3) / 4 * 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
     const int tile_w = blockIdx.x % tiles_w, tile_h = blockIdx.x / tiles_w;
     const int oh0 = tile_h * DN_TH, ow0 = tile_w * DN_TW;
     const int co0 = blockIdx.y * DN_BN;
-    const int b = blockIdx.z;
-    const int s = a.stride;
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1;       // split-K over input-channel chunks (small planes)
+    const int b = blockIdx.z / ksplit, ks = blockIdx.z - b * ksplit;
     const float* inb = a.in + (long)b * a.in_bs;
-    const int ih0 = oh0 * s - a.pad_t, iw0 = ow0 * s - a.pad_l;
+    const int ih0 = oh0 * S - a.pad_t, iw0 = ow0 * S - a.pad_l;
+    const unsigned in_cs = (unsigned)a.in_cs;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -44,58 +56,96 @@ __global__ __launch_bounds__(256, 2) void dn_conv_kernel(babe_dnconv_args a, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nrows = DN_KC * PH;
-    const int wslab4 = KHC * a.KW * DN_KC * (DN_BN / 4);          // float4 per weight slab
-    for (int ci0 = 0; ci0 < CinP; ci0 += DN_KC) {
-        __syncthreads();                                          // previous chunk's reads of Xs / Ws are done
-        // ---- input patch: one (channel, patch row) per wave iteration, lanes along the columns
-        for (int rr = wave; rr < nrows; rr += 4) {
-            const int ch = rr / PH, r = rr - ch * PH;
-            int ih = ih0 + r;
-            bool rok = ci0 + ch < a.Cin;
+    // per-thread patch slots: element e = tid + 256*j -> (channel, patch row, patch column); the column part of the
+    // source index does not change between steps
+    constexpr bool CACHE_COL = XJ <= 16;             // keep the reflected column index in registers when it is cheap
+    auto col_of = [&](int j) {
+        const int e = tid + 256 * j;
+        int iw = iw0 + e % PW;
+        if (a.pad_mode) {
+            if (iw < 0) iw = -iw;
+            if (iw >= a.IW) iw = 2 * (a.IW - 1) - iw;
+        }
+        return (e < NX && iw >= 0 && iw < a.IW) ? iw : -1;
+    };
+    int xoff[CACHE_COL ? XJ : 1];                    // iw (reflected) or -1
+    if constexpr (CACHE_COL) {
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) xoff[j] = col_of(j);
+    }
+    float xr[XJ];
+    f32x4 wr[WJ];
+    auto load_step = [&](int ci0, int kg) {
+        const int kh0 = kg * KHC;
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int e = tid + 256 * j;
+            const int rr = e / PW;
+            const int r = rr % PH, ch = rr / PH;
+            int ih = ih0 + kh0 + r;
             if (a.pad_mode) {
                 if (ih < 0) ih = -ih;
                 if (ih >= a.IH) ih = 2 * (a.IH - 1) - ih;
             }
-            rok = rok && ih >= 0 && ih < a.IH;
-            const float* src = inb + (long)(ci0 + ch < a.Cin ? ci0 + ch : 0) * a.in_cs + (long)(rok ? ih : 0) * a.IW;
-            float* dst = Xs + rr * PW;
-            for (int c = lane; c < PW; c += 64) {
-                int iw = iw0 + c;
-                if (a.pad_mode) {
-                    if (iw < 0) iw = -iw;
-                    if (iw >= a.IW) iw = 2 * (a.IW - 1) - iw;
-                }
-                const bool ok = rok && iw >= 0 && iw < a.IW;
-                dst[c] = ok ? src[iw] : 0.f;
-            }
+            int iw;
+            if constexpr (CACHE_COL) iw = xoff[j];
+            else iw = col_of(j);
+            const bool ok = iw >= 0 && ih >= 0 && ih < a.IH && ci0 + ch < a.Cin;
+            const unsigned off = ok ? (unsigned)(ci0 + ch) * in_cs + (unsigned)(ih * a.IW + iw) : 0u;   // < 2^32 elements
+            const float v = inb[off];
+            xr[j] = ok ? v : 0.f;
         }
-        for (int kh0 = 0; kh0 < a.KH; kh0 += KHC) {
-            if (kh0) __syncthreads();
-            // ---- weight slab [KHC][KW][8][64] from the packed [KH][KW][CinP][CoutP] image
-            for (int i = tid; i < wslab4; i += 256) {
-                const int c4 = i & 15;
-                const int rest = i >> 4;                          // (khl*KW + kw)*8 + ci_l
-                const int ci_l = rest & 7;
-                const int tap = rest >> 3;
-                const int khl = tap / a.KW, kw = tap - khl * a.KW;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kh0 + khl < a.KH)
-                    v = *reinterpret_cast<const f32x4*>(
-                        wq + (((long)((kh0 + khl) * a.KW + kw) * CinP + ci0 + ci_l) * CoutP + co0) + c4 * 4);
-                *reinterpret_cast<f32x4*>(Ws + rest * DN_BN + c4 * 4) = v;
-            }
-            __syncthreads();
-            const int khn = a.KH - kh0 < KHC ? a.KH - kh0 : KHC;
-            for (int khl = 0; khl < khn; ++khl) {
-                const float* xrow = Xs + (wave * s + kh0 + khl) * PW + l31 * s;
-                for (int kw = 0; kw < a.KW; ++kw) {
-                    const float* wt = Ws + (khl * a.KW + kw) * DN_KC * DN_BN + l31;
 #pragma unroll
-                    for (int st = 0; st < DN_KC / 2; ++st) {
+        for (int j = 0; j < WJ; ++j) {
+            int i = tid + 256 * j;
+            if (i > NW4 - 1) i = NW4 - 1;
+            const int c4 = i & 15;
+            const int rest = i >> 4;                              // (khl*KW + kw)*KC + ci_l
+            const int ci_l = rest % KC;
+            const int tap = rest / KC;
+            const int khl = tap / KW, kw = tap - khl * KW;
+            const int kh = kh0 + khl < KH ? kh0 + khl : KH - 1;   // rows past KH are never used by the MFMA loop
+            wr[j] = *reinterpret_cast<const f32x4*>(wq + ((unsigned)((kh * KW + kw) * CinP + ci0 + ci_l) * (unsigned)CoutP + co0 + c4 * 4));
+        }
+    };
+    auto store_step = [&]() {
+#pragma unroll
+        for (int j = 0; j < XJ; ++j)
+            if (tid + 256 * j < NX) Xs[tid + 256 * j] = xr[j];
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
+            if (tid + 256 * j < NW4) *reinterpret_cast<f32x4*>(Ws + (tid + 256 * j) * 4) = wr[j];
+    };
+
+    const int nchunks = CinP / KC;
+    const int per = (nchunks + ksplit - 1) / ksplit;
+    const int c_lo = ks * per, c_hi = c_lo + per < nchunks ? c_lo + per : nchunks;
+    const int nsteps = (c_hi > c_lo ? c_hi - c_lo : 0) * NKG;
+    int ci0 = c_lo * KC, kg = 0;
+    if (nsteps > 0) load_step(ci0, 0);
+    for (int step = 0; step < nsteps; ++step) {
+        __syncthreads();                                          // everyone finished reading the previous slab
+        store_step();
+        __syncthreads();
+        int nci = ci0, nkg = kg + 1;
+        if (nkg == NKG) {
+            nkg = 0;
+            nci += KC;
+        }
+        if (step + 1 < nsteps) load_step(nci, nkg);
+        const int khn = KH - kg * KHC < KHC ? KH - kg * KHC : KHC;
+#pragma unroll
+        for (int khl = 0; khl < KHC; ++khl) {
+            if (khl < khn) {
+                const float* xrow = Xs + (wave * S + khl) * PW + l31 * S;
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const float* wt = Ws + (khl * KW + kw) * KC * DN_BN + l31;
+#pragma unroll
+                    for (int st = 0; st < KC / 2; ++st) {
                         const int ch = 2 * st + h;
                         const float a0 = wt[ch * DN_BN], a1 = wt[ch * DN_BN + 32];
-                        const float b0 = xrow[ch * PH * PW + kw], b1 = xrow[ch * PH * PW + kw + 32 * s];
+                        const float b0 = xrow[ch * PH * PW + kw], b1 = xrow[ch * PH * PW + kw + 32 * S];
                         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -104,10 +154,28 @@ __global__ __launch_bounds__(256, 2) void dn_conv_kernel(babe_dnconv_args a, con
                 }
             }
         }
+        ci0 = nci;
+        kg = nkg;
     }
 
-    // ---- epilogue: bias, ELU, residual; output index = logical index * out_step + out_off (both axes)
     const int oh = oh0 + wave;
+    if (ksplit > 1) {
+        // raw partial sums [ks][b][co][OH][OW]; dn_splitk_finish_kernel adds them up and applies the epilogue
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int bt = 0; bt < 2; ++bt) {
+                const int ow = ow0 + bt * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (oh < a.OH && ow < a.OW && co < a.Cout)
+                        a.ws[(((long)(ks * a.B + b) * a.Cout + co) * a.OH + oh) * a.OW + ow] = acc[nt][bt][r];
+                }
+            }
+        return;
+    }
+    // ---- epilogue: bias, ELU, residual; output index = logical index * out_step + out_off (both axes)
     const int fh = oh * a.out_hstep + a.out_h0;
     const bool rowok = oh < a.OH && fh >= 0 && fh < a.out_H;
 #pragma unroll
@@ -129,6 +197,40 @@ __global__ __launch_bounds__(256, 2) void dn_conv_kernel(babe_dnconv_args a, con
                 }
             }
         }
+}
+
+// sum of the split-K partials + the conv epilogue
+__global__ void dn_splitk_finish_kernel(babe_dnconv_args a, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ow = (int)(i % a.OW);
+    long r = i / a.OW;
+    const int oh = (int)(r % a.OH);
+    r /= a.OH;
+    const int co = (int)(r % a.Cout), b = (int)(r / a.Cout);
+    float v = a.bias ? a.bias[co] : 0.f;
+    for (int ks = 0; ks < a.ksplit; ++ks) v += a.ws[(long)ks * total + i];
+    if (a.act) v = v > 0.f ? v : expm1f(v);
+    const int fh = oh * a.out_hstep + a.out_h0, fw = ow * a.out_wstep + a.out_w0;
+    if (fh < 0 || fh >= a.out_H || fw < 0 || fw >= a.out_W) return;
+    const long sp = (long)fh * a.out_W + fw;
+    if (a.res) v += a.res[(long)b * a.res_bs + (long)co * a.res_cs + sp];
+    a.out[(long)b * a.out_bs + (long)co * a.out_cs + sp] = v;
+}
+
+template <int KH, int KW, int S, int KHC, int KC>
+void dn_launch(const babe_dnconv_args& a, const float* wq, hipStream_t s) {
+    constexpr int PH = (DN_TH - 1) * S + KHC, PW = (DN_TW - 1) * S + KW;
+    const int CinP = (a.Cin + 31) / 32 * 32, CoutP = (a.Cout + 63) / 64 * 64;
+    const int tiles_w = cdiv(a.OW, DN_TW), tiles_h = cdiv(a.OH, DN_TH);
+    const size_t lds = ((size_t)(KC * PH * PW + 3) / 4 * 4 + (size_t)KHC * KW * KC * DN_BN) * sizeof(float);
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+    dim3 grid(tiles_w * tiles_h, CoutP / DN_BN, a.B * ksplit);
+    hipLaunchKernelGGL((dn_conv_kernel<KH, KW, S, KHC, KC>), grid, dim3(256), lds, s, a, wq, CinP, CoutP, tiles_w);
+    if (ksplit > 1) {
+        const long total = (long)a.B * a.Cout * a.OH * a.OW;
+        hipLaunchKernelGGL(dn_splitk_finish_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, a, total);
+    }
 }
 
 // mode 0: w [Cout][Cin][KH][KW] -> dst [KH][KW][CinP][CoutP]
@@ -260,7 +362,7 @@ __global__ void dn_istft_ola_kernel(const float* __restrict__ fr, float* __restr
 }  // namespace
 
 extern "C" long babe_dn_packed_size(int Cout, int Cin, int KH, int KW) {
-    return (long)KH * KW * ((Cin + 7) / 8 * 8) * ((Cout + 63) / 64 * 64);
+    return (long)KH * KW * ((Cin + 31) / 32 * 32) * ((Cout + 63) / 64 * 64);
 }
 
 extern "C" int babe_dn_pack_weights(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int mode, int ph,
@@ -269,7 +371,7 @@ extern "C" int babe_dn_pack_weights(const float* w, float* dst, int Cout, int Ci
     BABE_CHECK_ARG(mode == 0 || (mode == 1 && KH == 2 && KW == 2 && (ph | 1) == 1 && (pw | 1) == 1),
                    "dn_pack_weights: mode 1 packs one parity of a 4x4 stride-2 transposed conv as a 2x2 kernel");
     BABE_CHECK_ARG(KH >= 1 && KH <= 7 && KW >= 1 && KW <= 7, "dn_pack_weights: kernel %dx%d unsupported", KH, KW);
-    const int CinP = (Cin + 7) / 8 * 8, CoutP = (Cout + 63) / 64 * 64;
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
     const long total = (long)KH * KW * CinP * CoutP;
     hipLaunchKernelGGL(dn_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, Cin, KH,
                        KW, CinP, CoutP, mode, ph, pw, total);
@@ -287,14 +389,21 @@ extern "C" int babe_dn_conv2d(const babe_dnconv_args* ap, const float* w_packed,
                                        a.KW - 1 - a.pad_l < a.IW),
                    "dn_conv2d: reflect padding needs pad < input size (%dx%d)", a.IH, a.IW);
     BABE_CHECK_ARG(a.out_hstep >= 1 && a.out_wstep >= 1 && a.out_H > 0 && a.out_W > 0, "dn_conv2d: bad output mapping");
-    const int CinP = (a.Cin + 7) / 8 * 8, CoutP = (a.Cout + 63) / 64 * 64;
-    const int PH = (DN_TH - 1) * a.stride + a.KH, PW = (DN_TW - 1) * a.stride + a.KW;
-    const int KHC = a.KH * a.KW <= 16 ? a.KH : 1;
-    const int tiles_w = cdiv(a.OW, DN_TW), tiles_h = cdiv(a.OH, DN_TH);
-    const size_t lds = ((size_t)DN_KC * PH * PW + (size_t)KHC * a.KW * DN_KC * DN_BN) * sizeof(float);
-    dim3 grid(tiles_w * tiles_h, CoutP / DN_BN, a.B);
-    hipLaunchKernelGGL(dn_conv_kernel, grid, dim3(256), lds, (hipStream_t)stream, a, w_packed, CinP, CoutP, tiles_w, PH,
-                       PW, KHC);
+    BABE_CHECK_ARG(a.ksplit <= 1 || a.ws, "dn_conv2d: ksplit=%d needs a workspace of ksplit*B*Cout*OH*OW floats", a.ksplit);
+    BABE_CHECK_ARG((double)a.in_cs * a.Cin < 4.0e9, "dn_conv2d: one batch item of the input must stay below 2^32 elements");
+    hipStream_t s = (hipStream_t)stream;
+    const int key = a.KH * 100 + a.KW * 10 + a.stride;
+    switch (key) {
+        case 331: dn_launch<3, 3, 1, 3, 8>(a, w_packed, s); break;
+        case 771: dn_launch<7, 7, 1, 1, 8>(a, w_packed, s); break;
+        case 442: dn_launch<4, 4, 2, 1, 8>(a, w_packed, s); break;
+        case 221: dn_launch<2, 2, 1, 2, 8>(a, w_packed, s); break;
+        case 111: dn_launch<1, 1, 1, 1, 32>(a, w_packed, s); break;
+        default:
+            babe_set_error("dn_conv2d: kernel %dx%d stride %d is not one of the denoiser's shapes (3x3, 7x7, 1x1, 2x2 "
+                           "stride 1; 4x4 stride 2)", a.KH, a.KW, a.stride);
+            return BABE_ERR_UNSUPPORTED;
+    }
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

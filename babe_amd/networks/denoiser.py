@@ -26,7 +26,7 @@ class DnConvArgs(C.Structure):
                 ("res", C.c_void_p), ("res_bs", C.c_long), ("res_cs", C.c_long),
                 ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("OH", C.c_int), ("OW", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad_t", C.c_int), ("pad_l", C.c_int),
-                ("pad_mode", C.c_int), ("act", C.c_int)]
+                ("pad_mode", C.c_int), ("act", C.c_int), ("ksplit", C.c_int), ("ws", C.c_void_p)]
 
 
 _registered = False
@@ -123,6 +123,24 @@ def init_state_dict(cfg, seed=0):
     return sd
 
 
+_ws = {}
+
+
+def _split_k(a, dev):
+    """Planes too small to fill the GPU (deep U-Net levels) split the input channels over several workgroups per tile;
+    the partial sums pass through a cached workspace."""
+    tiles = -(-a.OH // 4) * -(-a.OW // 64) * -(-a.Cout // 64) * a.B
+    chunks = -(-a.Cin // 32) * 4 if (a.KH, a.KW) != (1, 1) else -(-a.Cin // 32)
+    ks = min(chunks, max(1, 512 // tiles), 32)
+    if ks <= 1 or chunks < 8:
+        return
+    n = ks * a.B * a.Cout * a.OH * a.OW
+    w = _ws.get(dev)
+    if w is None or w.numel() < n:
+        w = _ws[dev] = torch.empty(max(n, 1 << 22), device=dev)
+    a.ksplit, a.ws = ks, ptr(w)
+
+
 def _planes(t):
     assert t.dim() == 4 and t.dtype == torch.float32 and t.is_cuda
     assert t.stride(3) == 1 and t.stride(2) == t.shape[3], f"planes must be contiguous, got strides {t.stride()}"
@@ -174,6 +192,7 @@ def _conv(x, pc, out, *, stride=1, pad=None, reflect=True, act=False, res=None):
     a.B, a.Cin, a.Cout, a.OH, a.OW = B, Cin, pc.Cout, out.shape[2], out.shape[3]
     a.KH, a.KW, a.stride, a.pad_t, a.pad_l = pc.KH, pc.KW, stride, pt, pl
     a.pad_mode, a.act = (1 if reflect else 0), (1 if act else 0)
+    _split_k(a, x.device)
     check(lib().babe_dn_conv2d(C.byref(a), ptr(pc.w), stream()), "dn_conv2d")
 
 
@@ -190,6 +209,7 @@ def _tconv(x, pc, out, crop_h, crop_w):
         a.out_hstep, a.out_h0, a.out_wstep, a.out_w0 = 2, ph - crop_h, 2, pw - crop_w
         a.B, a.Cin, a.Cout, a.OH, a.OW = B, Cin, pc.Cout, IH + 1, IW + 1
         a.KH, a.KW, a.stride, a.pad_t, a.pad_l, a.pad_mode, a.act = 2, 2, 1, 1, 1, 0, 1
+        _split_k(a, x.device)
         check(lib().babe_dn_conv2d(C.byref(a), ptr(wq), stream()), "dn_conv2d(tconv)")
 
 

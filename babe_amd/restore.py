@@ -1,11 +1,15 @@
 """Command line: blind bandwidth extension of one wav file on the MI355X path.
 
     python -m babe_amd.restore in.wav out_dir [--ckpt weights.pt] [--precision f32|bf16x3|bf16] [--T 35]
+                               [--denoise [--denoiser-ckpt denoiser.pt]]
 
 Follows the reference's file-level flow (testing/blind_bwe_tester.py:321-577 formal_test_bwe, blind mode):
 read -> (resample is NOT done here: the file must already be at exp.sample_rate) -> normalise to sigma_norm std
 -> segments + blind restoration + cross-fade (babe_amd/testing/long_file.py) -> write wav + filter pickle.
 Without --ckpt the network has random weights (useful only to exercise the path).
+--denoise runs the denoiser pre-pass first (testing/denoise_and_bwe_tester.py:279-285: apply_denoiser on the whole file,
+then the BWE on its output); it needs the file at the denoiser's rate (sample_rate_denoiser == exp.sample_rate: the
+torchaudio resampling of the reference is not part of this build).
 """
 import argparse
 import os
@@ -24,6 +28,8 @@ def main():
     ap.add_argument("--audio-len", type=int, default=368368)
     ap.add_argument("--batch", type=int, default=8, help="segments restored per batch")
     ap.add_argument("--sigma-norm", type=float, default=0.1)
+    ap.add_argument("--denoise", action="store_true", help="denoiser pre-pass before the bandwidth extension")
+    ap.add_argument("--denoiser-ckpt", help="state_dict of networks.denoiser.MultiStage_denoise")
     a = ap.parse_args()
     from .config import default_args
     from .diff_params.edm import EDM
@@ -38,8 +44,18 @@ def main():
     y, sr = read_audio_file(a.wav)
     if sr != a.sample_rate:
         raise SystemExit(f"{a.wav} is sampled at {sr} Hz; resample it to {a.sample_rate} Hz first")
+    y = y.cuda()
+    if a.denoise:
+        from .networks.denoiser import MultiStage_denoise
+        from .testing.denoise import DenoiserPrepass
+        dargs = dict(sample_rate_denoiser=a.sample_rate, segment_size=5, stft_win_size=1024, stft_hop_size=256, depth=6,
+                     num_tfc=3, num_stages=2, use_SAM=True, use_fencoding=True, f_dim=513)   # blind_bwe_denoise*.yaml `denoiser:`
+        dnet = MultiStage_denoise(dargs)
+        if a.denoiser_ckpt:
+            dnet.load_state_dict(torch.load(a.denoiser_ckpt, map_location="cpu"))
+        y = DenoiserPrepass(dnet.to("cuda"), dargs, "cuda").apply_denoiser(y.unsqueeze(0))[0]
     std = float(y.std())
-    y = (y * (a.sigma_norm / std)).cuda()
+    y = y * (a.sigma_norm / std)
     sampler = BlindSampler(net, EDM(args), args, batch_semantics="per_clip")
     out, filt = restore_file(sampler, y, batch_size=a.batch)
     name = os.path.splitext(os.path.basename(a.wav))[0]

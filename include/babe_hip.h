@@ -205,9 +205,11 @@ typedef struct {
     float* out; long out_bs, out_cs; int out_H, out_W, out_hstep, out_h0, out_wstep, out_w0;
     const float* res; long res_bs, res_cs;
     int B, Cin, Cout, OH, OW, KH, KW, stride, pad_t, pad_l, pad_mode, act;
+    int ksplit;                  /* > 1: split the input channels over ksplit workgroups per tile (small planes); the */
+    float* ws;                   /* partial sums go through ws [ksplit][B][Cout][OH][OW] and a finishing pass */
 } babe_dnconv_args;
 int babe_dn_conv2d(const babe_dnconv_args* a, const float* w_packed, void* stream);
-/* mode 0: w [Cout][Cin][KH][KW] -> [KH][KW][ceil8(Cin)][ceil64(Cout)].  mode 1 (KH=KW=2): parity (ph,pw) of a
+/* mode 0: w [Cout][Cin][KH][KW] -> [KH][KW][ceil32(Cin)][ceil64(Cout)].  mode 1 (KH=KW=2): parity (ph,pw) of a
  * ConvTranspose2d weight [Cin][Cout][4][4] with stride 2: out[2m+p] = sum_a in[m-a] w[p+2a]. */
 int babe_dn_pack_weights(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int mode, int ph, int pw,
                          void* stream);
