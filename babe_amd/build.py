@@ -18,8 +18,23 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
+    """Compile what is out of date.  Safe to call from several processes at once (one rank per GPU calls it): a file
+    lock serialises them and the late comers find the library up to date."""
     if not force and not needs_build():
         return OUT
+    import fcntl
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return OUT
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
@@ -49,10 +64,12 @@ def build(force=False, verbose=True):
             print(out)
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    tmp = OUT + f".tmp{os.getpid()}"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, OUT)               # atomic: a concurrent dlopen never sees a half-written library
     return OUT
 
 
