@@ -11,13 +11,13 @@ namespace {
 // grid (nbands, B), 256 threads
 __global__ __launch_bounds__(256) void band_analysis_kernel(babe_cqt_bands bd, const float* __restrict__ spec,
                                                             const float* __restrict__ win) {
-    __shared__ float2 a[4096];
+    __shared__ float2 a[FFT_LDS_LEN(4096)];
     const int k = blockIdx.x, b = blockIdx.y;
     const int c = bd.c[k], M = bd.M[k], woff = bd.woff[k], lt = bd.log2T[k];
     const int T = 1 << lt;
     const float* sre = spec + (long)b * 2 * bd.KX;
     const float* sim = sre + bd.KX;
-    for (int i = threadIdx.x; i < T; i += blockDim.x) a[i] = make_float2(0.f, 0.f);
+    for (int i = threadIdx.x; i < FFT_LDS_LEN(T); i += blockDim.x) a[i] = make_float2(0.f, 0.f);
     __syncthreads();
     const int half = M >> 1;
     for (int mi = threadIdx.x; mi < M; mi += blockDim.x) {
@@ -30,32 +30,33 @@ __global__ __launch_bounds__(256) void band_analysis_kernel(babe_cqt_bands bd, c
         else v = make_float2(sre[bd.L - n], -sim[bd.L - n]);
         const float w = win[woff + mi];
         const unsigned pos = (unsigned)(m & (T - 1));
-        a[bitrev_n(pos, lt)] = make_float2(v.x * w, v.y * w);
+        a[fft_at(bitrev_n(pos, lt))] = make_float2(v.x * w, v.y * w);
     }
     fft_lds_inplace(a, lt, reinterpret_cast<const float2*>(bd.tw4096), +1);
     float* out = bd.coef[bd.oct[k]] + ((long)b * 2 * bd.binsoct + bd.binoct[k]) * T;
     const long imoff = (long)bd.binsoct * T;
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
-        out[i] = a[i].x;
-        out[imoff + i] = a[i].y;
+        const float2 v = a[fft_at(i)];
+        out[i] = v.x;
+        out[imoff + i] = v.y;
     }
 }
 
 __global__ __launch_bounds__(256) void band_synthesis_kernel(babe_cqt_bands bd, float* __restrict__ bs,
                                                              const float* __restrict__ win, long bs_stride) {
-    __shared__ float2 a[4096];
+    __shared__ float2 a[FFT_LDS_LEN(4096)];
     const int k = blockIdx.x, b = blockIdx.y;
     const int M = bd.M[k], woff = bd.woff[k], lt = bd.log2T[k];
     const int T = 1 << lt;
     const float* in = bd.coef[bd.oct[k]] + ((long)b * 2 * bd.binsoct + bd.binoct[k]) * T;
     const long imoff = (long)bd.binsoct * T;
-    for (int i = threadIdx.x; i < T; i += blockDim.x) a[bitrev_n(i, lt)] = make_float2(in[i], in[imoff + i]);
+    for (int i = threadIdx.x; i < T; i += blockDim.x) a[fft_at(bitrev_n(i, lt))] = make_float2(in[i], in[imoff + i]);
     fft_lds_inplace(a, lt, reinterpret_cast<const float2*>(bd.tw4096), -1);
     float2* o = reinterpret_cast<float2*>(bs) + (long)b * bs_stride + woff;
     const int half = M >> 1;
     for (int mi = threadIdx.x; mi < M; mi += blockDim.x) {
         const int m = mi - half;
-        const float2 v = a[m & (T - 1)];
+        const float2 v = a[fft_at(m & (T - 1))];
         const float w = win[woff + mi];
         o[mi] = make_float2(v.x * w, v.y * w);
     }

@@ -301,44 +301,45 @@ __device__ __forceinline__ float dn_hamming(int i, int n) { return 0.54f - 0.46f
 // STFT, center=False, periodic Hamming, hop = n/4: X[b][0|1][t][k], k <= n/2.  grid (frames, B)
 __global__ __launch_bounds__(256) void dn_stft_kernel(const float* __restrict__ x, long x_bs, int L, float* __restrict__ X,
                                                       int log2n, int hop, int frames, const float2* __restrict__ tw) {
-    __shared__ float2 a[1024];
+    __shared__ float2 a[FFT_LDS_LEN(1024)];
     const int n = 1 << log2n, nb = n / 2 + 1;
     const int t = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (long)b * x_bs;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const long sidx = (long)t * hop + i;
         const float v = sidx < L ? xb[sidx] : 0.f;
-        a[bitrev_n(i, log2n)] = make_float2(v * dn_hamming(i, n), 0.f);
+        a[fft_at(bitrev_n(i, log2n))] = make_float2(v * dn_hamming(i, n), 0.f);
     }
     fft_lds_inplace(a, log2n, tw, -1);
     float* re = X + (((long)b * 2 + 0) * frames + t) * nb;
     float* im = X + (((long)b * 2 + 1) * frames + t) * nb;
     for (int k = threadIdx.x; k < nb; k += blockDim.x) {
-        re[k] = a[k].x;
-        im[k] = a[k].y;
+        const float2 v = a[fft_at(k)];
+        re[k] = v.x;
+        im[k] = v.y;
     }
 }
 
 // frames[b][t][i] = w[i] * irfft(P[b][:][t][:])[i]
 __global__ __launch_bounds__(256) void dn_istft_frames_kernel(const float* __restrict__ P, float* __restrict__ fr,
                                                               int log2n, int frames, const float2* __restrict__ tw) {
-    __shared__ float2 a[1024];
+    __shared__ float2 a[FFT_LDS_LEN(1024)];
     const int n = 1 << log2n, nb = n / 2 + 1;
     const int t = blockIdx.x, b = blockIdx.y;
     const float* re = P + (((long)b * 2 + 0) * frames + t) * nb;
     const float* im = P + (((long)b * 2 + 1) * frames + t) * nb;
     for (int k = threadIdx.x; k < nb; k += blockDim.x) {
         if (k == 0 || k == n / 2) {
-            a[bitrev_n(k, log2n)] = make_float2(re[k], 0.f);          // C2R ignores Im at DC / Nyquist
+            a[fft_at(bitrev_n(k, log2n))] = make_float2(re[k], 0.f);          // C2R ignores Im at DC / Nyquist
         } else {
-            a[bitrev_n(k, log2n)] = make_float2(re[k], im[k]);
-            a[bitrev_n(n - k, log2n)] = make_float2(re[k], -im[k]);
+            a[fft_at(bitrev_n(k, log2n))] = make_float2(re[k], im[k]);
+            a[fft_at(bitrev_n(n - k, log2n))] = make_float2(re[k], -im[k]);
         }
     }
     fft_lds_inplace(a, log2n, tw, +1);
     float* o = fr + ((long)b * frames + t) * n;
     const float inv = 1.f / (float)n;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = a[i].x * inv * dn_hamming(i, n);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = a[fft_at(i)].x * inv * dn_hamming(i, n);
 }
 
 // y[b][j] = sum_t frames[b][t][j - t*hop] / sum_t w^2[j - t*hop]      (torch.istft, center=False), j < Lout

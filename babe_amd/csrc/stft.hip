@@ -18,7 +18,7 @@ __device__ __forceinline__ float hamming_periodic(int i, int n) {
 __global__ __launch_bounds__(256) void stft_fwd_kernel(const float* __restrict__ x, long x_bs, int L,
                                                        const float* __restrict__ pre, float* __restrict__ spec,
                                                        int log2n, int frames, const float2* __restrict__ tw) {
-    __shared__ float2 a[4096];
+    __shared__ float2 a[FFT_LDS_LEN(4096)];
     const int n = 1 << log2n, hop = n >> 1;
     const int t = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (long)b * x_bs;
@@ -27,19 +27,19 @@ __global__ __launch_bounds__(256) void stft_fwd_kernel(const float* __restrict__
         const int s = s0 + i;
         float v = (s < L) ? xb[s] : 0.f;
         if (pre) v *= pre[s];
-        a[bitrev_n(i, log2n)] = make_float2(v * hamming_periodic(i, n), 0.f);
+        a[fft_at(bitrev_n(i, log2n))] = make_float2(v * hamming_periodic(i, n), 0.f);
     }
     fft_lds_inplace(a, log2n, tw, -1);
     const int nb = hop + 1;
     float2* o = reinterpret_cast<float2*>(spec) + ((long)b * frames + t) * nb;
-    for (int k = threadIdx.x; k < nb; k += blockDim.x) o[k] = a[k];
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) o[k] = a[fft_at(k)];
 }
 
 __global__ __launch_bounds__(256) void spec_filter_istft_kernel(const float* __restrict__ spec,
                                                                 const float* __restrict__ H, long H_bs,
                                                                 float* __restrict__ fr, int log2n, int frames,
                                                                 const float2* __restrict__ tw) {
-    __shared__ float2 a[4096];
+    __shared__ float2 a[FFT_LDS_LEN(4096)];
     const int n = 1 << log2n, hop = n >> 1;
     const int t = blockIdx.x, b = blockIdx.y;
     const int nb = hop + 1;
@@ -51,16 +51,16 @@ __global__ __launch_bounds__(256) void spec_filter_istft_kernel(const float* __r
         v.x *= h;
         v.y *= h;
         if (k == 0 || k == hop) {
-            a[bitrev_n(k, log2n)] = make_float2(v.x, 0.f);          // irfft ignores Im at DC / Nyquist
+            a[fft_at(bitrev_n(k, log2n))] = make_float2(v.x, 0.f);          // irfft ignores Im at DC / Nyquist
         } else {
-            a[bitrev_n(k, log2n)] = v;
-            a[bitrev_n(n - k, log2n)] = make_float2(v.x, -v.y);
+            a[fft_at(bitrev_n(k, log2n))] = v;
+            a[fft_at(bitrev_n(n - k, log2n))] = make_float2(v.x, -v.y);
         }
     }
     fft_lds_inplace(a, log2n, tw, +1);
     float* o = fr + ((long)b * frames + t) * n;
     const float inv = 1.f / (float)n;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = a[i].x * inv * hamming_periodic(i, n);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = a[fft_at(i)].x * inv * hamming_periodic(i, n);
 }
 
 // grid (nblk, B)
