@@ -19,7 +19,11 @@ def _view(t):
 
 
 PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
-WINOGRAD = os.environ.get("BABE_CONV_WINO", "1") != "0"      # debug switch: 0 forces the direct fp32 kernel
+# debug switch for the (5,3) fp32 convs: 0 = direct kernel only, 2 = Winograd F(2,3) only, 4 (default) = F(4,3) where the
+# problem qualifies, F(2,3) otherwise
+_W = os.environ.get("BABE_CONV_WINO", "4")
+WINOGRAD = _W != "0"
+WINOGRAD4 = _W not in ("0", "2", "1")
 
 
 class PackedConv:
@@ -65,6 +69,12 @@ class PackedConv:
             self.bwd_wino = torch.empty(L.babe_conv_packed_size_wino(self.Cout, self.Cin, self.KH, 1), device=w.device)
             check(L.babe_conv_pack_weights_wino(ptr(w), ptr(self.fwd_wino), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack_wino")
             check(L.babe_conv_pack_weights_wino(ptr(w), ptr(self.bwd_wino), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino")
+        self.fwd_wino4 = self.bwd_wino4 = None
+        if self.KW == 3 and WINOGRAD4:
+            self.fwd_wino4 = torch.empty(L.babe_conv_packed_size_wino4(self.Cout, self.Cin, self.KH, 0), device=w.device)
+            self.bwd_wino4 = torch.empty(L.babe_conv_packed_size_wino4(self.Cout, self.Cin, self.KH, 1), device=w.device)
+            check(L.babe_conv_pack_weights_wino4(ptr(w), ptr(self.fwd_wino4), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack_wino4")
+            check(L.babe_conv_pack_weights_wino4(ptr(w), ptr(self.bwd_wino4), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino4")
 
 
 def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=None, oscale=None, alpha=1.0, rbeta=0.0):
@@ -101,6 +111,8 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
     a.KH, a.KW, a.dil = pc.KH, pc.KW, dil
     if pc.splits:
         check(lib().babe_conv2d_bf16(C.byref(a), ptr(wq), pc.splits, stream()), "conv2d_bf16")
+    elif getattr(pc, "fwd_wino4", None) is not None and lib().babe_conv2d_wino4_supported(C.byref(a)):
+        check(lib().babe_conv2d_wino4(C.byref(a), ptr(pc.bwd_wino4 if transpose else pc.fwd_wino4), stream()), "conv2d_wino4")
     elif getattr(pc, "fwd_wino", None) is not None and lib().babe_conv2d_wino_supported(C.byref(a)):
         check(lib().babe_conv2d_wino(C.byref(a), ptr(pc.bwd_wino if transpose else pc.fwd_wino), stream()), "conv2d_wino")
     else:

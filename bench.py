@@ -209,9 +209,10 @@ def main():
         dtype = {"f32": "f32", "bf16x3": "bf16x3 (bf16 MFMA on hi/lo-split operands, fp32 storage+accumulate)",
                  "bf16": "bf16 (bf16 MFMA, fp32 storage+accumulate)"}[a.precision]
         peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "f32" else 2500.0
-        kname = ("babe_conv2d launches of the UNet: conv_wino_kernel / conv_wino_pp_kernel (Winograd F(2,3)-along-time, "
-                 "fp32 v_mfma_f32_32x32x2_f32) for the (5,3) layers, conv_mfma_kernel for (1,1); fwd + input-VJP; "
-                 "achieved counts the ALGORITHMIC (direct-convolution) flops"
+        kname = ("babe_conv2d launches of the UNet: conv_wino4_kernel (Winograd F(4,3)-along-time, fp32 "
+                 "v_mfma_f32_32x32x2_f32; F(2,3) / direct fallbacks) for the (5,3) layers, conv_mfma_kernel for (1,1); fwd + "
+                 "input-VJP; achieved counts the ALGORITHMIC (direct-convolution) flops - the matrix pipe executes half of "
+                 "them on the (5,3) layers"
                  if a.precision == "f32" else
                  "conv_bf16_kernel (v_mfma_f32_32x32x16_bf16; %s products per k-block; achieved counts ALGORITHMIC flops)"
                  % ("3" if a.precision == "bf16x3" else "1"))

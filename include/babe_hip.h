@@ -56,6 +56,15 @@ int babe_conv2d_wino_supported(const babe_conv_args* a);
 int babe_conv_pack_weights_wino(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
                                 void* stream);
 long babe_conv_packed_size_wino(int Cout, int Cin, int KH, int transpose_flip);
+/* Winograd F(4,3)-along-time variant (csrc/conv_wino4.hip): half of the direct kernel's MFMA work, fp32, about 2.5x the
+ * rounding error of F(2,3) (1e-6 relative).  w_wino4 from babe_conv_pack_weights_wino4:
+ * [KH][ceil8(Cin)][2][ceil32(Cout)][4].  Needs T % 4 == 0, 16-byte aligned in/out/res rows, Cout in 64, 96 or a multiple
+ * of 128 (after rounding up to 32). */
+int babe_conv2d_wino4(const babe_conv_args* a, const float* w_wino4, void* stream);
+int babe_conv2d_wino4_supported(const babe_conv_args* a);
+int babe_conv_pack_weights_wino4(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
+                                 void* stream);
+long babe_conv_packed_size_wino4(int Cout, int Cin, int KH, int transpose_flip);
 /* Measurement hook (bench.py): when enabled every babe_conv2d launch is bracketed by HIP events on its
  * stream; read returns the summed kernel time, the summed ALGORITHMIC flops (2*B*Cout*Cin*KH*KW*F*T with the
  * unpadded channel counts) and the launch count, then resets. */
