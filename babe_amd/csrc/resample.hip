@@ -35,18 +35,7 @@ __device__ __forceinline__ float up_gpad(const float* gy, int j, int T2) {
     return s;
 }
 
-// grid: (ceil(Tout/256), F, B*C)
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, long in_bs, long in_cs,
-                                                       float* __restrict__ out, long out_bs, long out_cs, int C,
-                                                       int T, int mode, float alpha, float beta) {
-    const int f = blockIdx.y;
-    const int b = blockIdx.z / C, c = blockIdx.z % C;
-    const int Tin = (mode == 0 || mode == 1) ? T : (mode == 2 ? T / 2 : 2 * T);
-    const int Tout = (mode == 0) ? T / 2 : (mode == 1 ? 2 * T : T);
-    const float* x = in + (long)b * in_bs + (long)c * in_cs + (long)f * Tin;
-    float* y = out + (long)b * out_bs + (long)c * out_cs + (long)f * Tout;
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= Tout) return;
+__device__ __forceinline__ float resample_one(const float* __restrict__ x, int n, int T, int mode) {
     float s = 0.f;
     if (mode == 0) {
 #pragma unroll
@@ -71,7 +60,73 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
         if (n >= 1 && n <= 2) s += up_gpad(x, 2 - n, T2);
         if (n >= T - 3 && n <= T - 2) s += up_gpad(x, 2 * T - n, T2);
     }
-    y[n] = (beta != 0.f) ? alpha * s + beta * y[n] : alpha * s;
+    return s;
+}
+
+// One thread = V consecutive outputs of one row; (row, position) come from a flat index over the F*Tout outputs of a
+// (b, c) plane, so the short rows of the deep UNet levels (T = 64) still fill whole workgroups.  grid: (blocks, B*C)
+template <int V>
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, long in_bs, long in_cs,
+                                                       float* __restrict__ out, long out_bs, long out_cs, int C, int F,
+                                                       int T, int mode, float alpha, float beta) {
+    const int b = blockIdx.y / C, c = blockIdx.y % C;
+    const int Tin = (mode == 0 || mode == 1) ? T : (mode == 2 ? T / 2 : 2 * T);
+    const int Tout = (mode == 0) ? T / 2 : (mode == 1 ? 2 * T : T);
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (i >= (long)F * Tout) return;
+    const int f = (int)(i / Tout);
+    const int n0 = (int)(i - (long)f * Tout);
+    const float* x = in + (long)b * in_bs + (long)c * in_cs + (long)f * Tin;
+    float* y = out + (long)b * out_bs + (long)c * out_cs + (long)f * Tout + n0;
+    float s[V];
+    bool fast = false;
+    if constexpr (V == 4) {
+        // interior fast paths: the 4 outputs share one register window of the source row (14 or 6 loads instead of 32 /
+        // 16); same tap order as resample_one, so the results are identical
+        if (mode == 0 || mode == 3) {                       // y[n] = sum_k h[k] src[2n - 3 + k]
+            const bool inner = mode == 0 ? (2 * n0 - 3 >= 0 && 2 * n0 + 10 <= T - 1) : (n0 >= 3 && n0 + 3 <= T - 4);
+            if (inner) {
+                const float* p = x + 2 * n0 - 3;
+                float w[14];
+#pragma unroll
+                for (int j = 0; j < 14; ++j) w[j] = p[j];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a += kH[k] * w[2 * v + k];
+                    s[v] = alpha * a;
+                }
+                fast = true;
+            }
+        } else {                                            // 4-tap polyphase: even n taps (1,3,5,7), odd n taps (0,2,4,6)
+            const int m = n0 >> 1;
+            const int len = mode == 1 ? T : T / 2;          // source row length
+            const bool inner = m - 2 >= 0 && m + 3 <= len - 1 && (mode == 1 || (n0 >= 4 && n0 + 3 <= T - 5));
+            if (inner) {
+                float w[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) w[j] = x[m - 2 + j];     // w[j] = src[m - 2 + j]
+                s[0] = alpha * (kH[1] * w[3] + kH[3] * w[2] + kH[5] * w[1] + kH[7] * w[0]);
+                s[1] = alpha * (kH[0] * w[4] + kH[2] * w[3] + kH[4] * w[2] + kH[6] * w[1]);
+                s[2] = alpha * (kH[1] * w[4] + kH[3] * w[3] + kH[5] * w[2] + kH[7] * w[1]);
+                s[3] = alpha * (kH[0] * w[5] + kH[2] * w[4] + kH[4] * w[3] + kH[6] * w[2]);
+                fast = true;
+            }
+        }
+    }
+    if (!fast) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[v] = alpha * resample_one(x, n0 + v, T, mode);
+    }
+    if constexpr (V == 4) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 o = {s[0], s[1], s[2], s[3]};
+        if (beta != 0.f) o += beta * *reinterpret_cast<const f32x4*>(y);
+        *reinterpret_cast<f32x4*>(y) = o;
+    } else {
+        y[0] = (beta != 0.f) ? s[0] + beta * y[0] : s[0];
+    }
 }
 }  // namespace
 
@@ -80,10 +135,17 @@ extern "C" int babe_resample(const float* in, long in_bs, long in_cs, float* out
     BABE_CHECK_ARG(in && out && B > 0 && C > 0 && F > 0, "resample: bad arguments");
     BABE_CHECK_ARG(mode >= 0 && mode <= 3, "resample: bad mode %d", mode);
     BABE_CHECK_ARG(T >= 8 && (T % 2) == 0, "resample: T=%d unsupported (need even T >= 8)", T);
-    BABE_CHECK_ARG((long)B * C <= 65535 && F <= 65535, "resample: grid too large");
+    BABE_CHECK_ARG((long)B * C <= 65535, "resample: grid too large");
     const int Tout = (mode == 0) ? T / 2 : (mode == 1 ? 2 * T : T);
-    hipLaunchKernelGGL(resample_kernel, dim3(cdiv(Tout, 256), F, B * C), dim3(256), 0, (hipStream_t)stream, in, in_bs,
-                       in_cs, out, out_bs, out_cs, C, T, mode, alpha, beta);
+    // 4 outputs per thread (16-byte stores) when the output rows keep 16-byte alignment
+    const bool v4 = (Tout % 4 == 0) && (((uintptr_t)out & 15) == 0) && (out_bs % 4 == 0) && (out_cs % 4 == 0);
+    const long total = (long)F * Tout;
+    if (v4)
+        hipLaunchKernelGGL(resample_kernel<4>, dim3(cdiv(total / 4, 256), B * C), dim3(256), 0, (hipStream_t)stream, in,
+                           in_bs, in_cs, out, out_bs, out_cs, C, F, T, mode, alpha, beta);
+    else
+        hipLaunchKernelGGL(resample_kernel<1>, dim3(cdiv(total, 256), B * C), dim3(256), 0, (hipStream_t)stream, in, in_bs,
+                           in_cs, out, out_bs, out_cs, C, F, T, mode, alpha, beta);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }
