@@ -15,17 +15,26 @@ extern "C" const char* babe_last_error(void) { return g_err; }
 extern "C" const char* babe_version(void) { return "babe_hip 0.1 (gfx950)"; }
 
 namespace {
-// grid: (blocks over T, F, B*C)
+// y = alpha*x + beta*y over [B][C] planes of n = F*T contiguous floats (rows are contiguous, so a frequency sub-view
+// is still one contiguous run per plane).  grid: (blocks over n/V, B*C); V = 4 when every plane keeps 16-byte alignment.
+template <int V>
 __global__ __launch_bounds__(256) void axpby4d_kernel(const float* __restrict__ in, long in_bs, long in_cs,
-                                                      float* __restrict__ out, long out_bs, long out_cs, int C,
-                                                      int T, float alpha, float beta) {
-    const int f = blockIdx.y;
-    const int b = blockIdx.z / C, c = blockIdx.z % C;
-    const float* x = in + (long)b * in_bs + (long)c * in_cs + (long)f * T;
-    float* y = out + (long)b * out_bs + (long)c * out_cs + (long)f * T;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
-        const float v = alpha * x[t];
-        y[t] = (beta != 0.f) ? v + beta * y[t] : v;
+                                                      float* __restrict__ out, long out_bs, long out_cs, int C, long n,
+                                                      float alpha, float beta) {
+    const int b = blockIdx.y / C, c = blockIdx.y % C;
+    const float* x = in + (long)b * in_bs + (long)c * in_cs;
+    float* y = out + (long)b * out_bs + (long)c * out_cs;
+    const long stride = (long)gridDim.x * blockDim.x * V;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += stride) {
+        if constexpr (V == 4) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            f32x4 v = alpha * *reinterpret_cast<const f32x4*>(x + i);
+            if (beta != 0.f) v += beta * *reinterpret_cast<const f32x4*>(y + i);
+            *reinterpret_cast<f32x4*>(y + i) = v;
+        } else {
+            const float v = alpha * x[i];
+            y[i] = (beta != 0.f) ? v + beta * y[i] : v;
+        }
     }
 }
 
@@ -64,10 +73,22 @@ extern "C" int babe_axpby4d(const float* in, long in_bs, long in_cs, float* out,
                             int C, int F, int T, float alpha, float beta, void* stream) {
     BABE_CHECK_ARG(in && out && B > 0 && C > 0 && F > 0 && T > 0, "axpby4d: bad arguments");
     BABE_CHECK_ARG((long)B * C <= 65535 && F <= 65535, "axpby4d: grid too large");
-    int bx = cdiv(T, 256);
-    if (bx > 16) bx = 16;
-    hipLaunchKernelGGL(axpby4d_kernel, dim3(bx, F, B * C), dim3(256), 0, (hipStream_t)stream, in, in_bs, in_cs, out,
-                       out_bs, out_cs, C, T, alpha, beta);
+    const long n = (long)F * T;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const bool v4 = (n % 4 == 0) && al16(in) && al16(out) && in_bs % 4 == 0 && in_cs % 4 == 0 && out_bs % 4 == 0 &&
+                    out_cs % 4 == 0;
+    BABE_CHECK_ARG((long)B * C <= 65535, "axpby4d: grid too large");
+    if (v4) {
+        int bx = cdiv(n / 4, 256);
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(axpby4d_kernel<4>, dim3(bx, B * C), dim3(256), 0, (hipStream_t)stream, in, in_bs, in_cs, out,
+                           out_bs, out_cs, C, n, alpha, beta);
+    } else {
+        int bx = cdiv(n, 256);
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(axpby4d_kernel<1>, dim3(bx, B * C), dim3(256), 0, (hipStream_t)stream, in, in_bs, in_cs, out,
+                           out_bs, out_cs, C, n, alpha, beta);
+    }
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }
