@@ -80,7 +80,7 @@ __device__ __forceinline__ void conv_epilogue(const babe_conv_args& a, f32x16 (&
 }
 
 struct ConvGeom {
-    int CinP, CoutP, pt_log2, pr_log2, tiles_t, prio_mode;
+    int CinP, CoutP, pt_log2, pr_log2, tiles_t;
 };
 
 template <int N> struct AVec;
@@ -138,20 +138,6 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
     const int h = lane >> 5;
     const int l31 = lane & 31;
 
-    if (g.prio_mode) {
-        // de-correlate the co-resident waves of a SIMD: all blocks run the same barrier-separated program and would
-        // otherwise reach their (MFMA-free) staging phases together.  Static priority = hardware wave slot.
-        unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u;   // HW_REG_HW_ID.WAVE_ID[1:0]
-        if (g.prio_mode == 2) {        // one priority per BLOCK (the slot of its first wave)
-            if (threadIdx.x == 0) smem[0] = __uint_as_float(slot);
-            __syncthreads();
-            slot = __builtin_amdgcn_readfirstlane(__float_as_uint(smem[0]));
-            __syncthreads();
-        }
-        if (slot == 1) __builtin_amdgcn_s_setprio(1);
-        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
-        else if (slot == 3) __builtin_amdgcn_s_setprio(3);
-    }
     f32x16 acc[NT][WP];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -333,8 +319,7 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
             while (nkh < a.KH && !kh_valid(nkh)) ++nkh;
         }
         const bool has_next = nkh < a.KH;
-        const bool dbg_nostage = g.prio_mode & 4, dbg_nobar = g.prio_mode & 8;     // timing ablations only
-        if (has_next && !dbg_nostage) load_chunk(nkh, nci);      // global loads stay in flight under the MFMAs below
+        if (has_next) load_chunk(nkh, nci);      // global loads stay in flight under the MFMAs below
         const float* Xs = smem + cur * BUF;
         // operand registers are prefetched one k-pair ahead of the MFMAs that consume them
         float av[2][NT], bv[2][WP];
@@ -359,8 +344,8 @@ __global__ __launch_bounds__(256, (WP == 1 ? 4 : 2)) void conv_mfma_kernel(babe_
                 for (int wp = 0; wp < WP; ++wp)
                     acc[nt][wp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][nt], bv[c][wp], acc[nt][wp], 0, 0, 0);
         }
-        if (has_next && !dbg_nostage) store_chunk(smem + (cur ^ 1) * BUF);
-        if (!dbg_nobar) __syncthreads();
+        if (has_next) store_chunk(smem + (cur ^ 1) * BUF);
+        __syncthreads();
         if (!has_next) break;
         kh = nkh;
         ci0 = nci;
@@ -427,14 +412,6 @@ int launch_conv(const babe_conv_args& a, ConvGeom g, hipStream_t s) {
     const int tiles_f = cdiv(a.F, PR);
     dim3 grid(g.tiles_t * tiles_f, g.CoutP / (NT * 32), a.B);
     size_t lds = 2 * ((size_t)((KC * PR * (PT + (VEC ? 8 : 2)) + 3) & ~3) + (size_t)KW * KC * NT * 32) * sizeof(float);
-    {   // occupancy cap (blocks per CU) by over-allocating LDS: BABE_CONV_OCC=n (experiment knob)
-        static const char* oc = getenv("BABE_CONV_OCC");
-        const int occ = oc ? atoi(oc) : 0;
-        if (occ > 0) {
-            const size_t need = (size_t)(160 * 1024) / (occ + 1) + 64;
-            if (lds < need) lds = need;
-        }
-    }
     hipLaunchKernelGGL((conv_mfma_kernel<NT, WP, KC, KW, VEC>), grid, dim3(256), lds, s, a, g);
     return 0;
 }
@@ -528,10 +505,6 @@ extern "C" int babe_conv2d(const babe_conv_args* ap, void* stream) {
                    "conv2d: kernel %dx%d unsupported (need 5x3 or 1x1)", a.KH, a.KW);
     BABE_CHECK_ARG(!a.in2 || (a.cin_split > 0 && a.cin_split < a.Cin), "conv2d: bad cin_split");
     ConvGeom g;
-    {
-        static const char* pm = getenv("BABE_CONV_PRIO");
-        g.prio_mode = pm ? atoi(pm) : 0;
-    }
     g.CinP = (a.Cin + 7) / 8 * 8;
     g.CoutP = (a.Cout + 31) / 32 * 32;
     const int n32 = g.CoutP / 32;
