@@ -9,7 +9,7 @@
 namespace {
 
 // grid (nbands, B), 256 threads
-__global__ __launch_bounds__(256) void band_analysis_kernel(babe_cqt_bands bd, const float* __restrict__ spec,
+__global__ __launch_bounds__(512) void band_analysis_kernel(babe_cqt_bands bd, const float* __restrict__ spec,
                                                             const float* __restrict__ win) {
     __shared__ float2 a[FFT_LDS_LEN(4096)];
     const int k = blockIdx.x, b = blockIdx.y;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void band_analysis_kernel(babe_cqt_bands bd, c
     }
 }
 
-__global__ __launch_bounds__(256) void band_synthesis_kernel(babe_cqt_bands bd, float* __restrict__ bs,
+__global__ __launch_bounds__(512) void band_synthesis_kernel(babe_cqt_bands bd, float* __restrict__ bs,
                                                              const float* __restrict__ win, long bs_stride) {
     __shared__ float2 a[FFT_LDS_LEN(4096)];
     const int k = blockIdx.x, b = blockIdx.y;
@@ -197,7 +197,7 @@ extern "C" int babe_cqt_band_analysis(const babe_cqt_bands* bd, const float* spe
                                       void* stream) {
     if (check_bands(bd)) return BABE_ERR_ARG;
     BABE_CHECK_ARG(spec && win && B > 0, "cqt_band_analysis: bad arguments");
-    hipLaunchKernelGGL(band_analysis_kernel, dim3(bd->nbands, B), dim3(256), 0, (hipStream_t)stream, *bd, spec, win);
+    hipLaunchKernelGGL(band_analysis_kernel, dim3(bd->nbands, B), dim3(512), 0, (hipStream_t)stream, *bd, spec, win);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }
@@ -206,7 +206,7 @@ extern "C" int babe_cqt_band_synthesis(const babe_cqt_bands* bd, float* bs, cons
                                        void* stream) {
     if (check_bands(bd)) return BABE_ERR_ARG;
     BABE_CHECK_ARG(bs && win && B > 0, "cqt_band_synthesis: bad arguments");
-    hipLaunchKernelGGL(band_synthesis_kernel, dim3(bd->nbands, B), dim3(256), 0, (hipStream_t)stream, *bd, bs, win,
+    hipLaunchKernelGGL(band_synthesis_kernel, dim3(bd->nbands, B), dim3(512), 0, (hipStream_t)stream, *bd, bs, win,
                        bs_stride);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
