@@ -121,6 +121,7 @@ def test_conv2d_two_sources_and_views(ops):
     (1, 128, 128, 128, 33, 128, 16),  # 128co x 128pos variant, ragged F
     (2, 5, 0, 20, 17, 20, 1),         # channel padding on both sides
     (1, 72, 0, 256, 9, 272, 2),       # two 128-channel blocks, T not a power of two, Cin % 8 == 0 only
+    (1, 20, 44, 64, 12, 16, 8),       # source split inside an 8-channel slab, shortest rows (T = 16), taps skipped
 ])
 def test_conv2d_winograd_vs_direct_and_oracle(ops, B, C1, C2, Cout, Fq, T, dil):
     """Winograd F(2,3)-along-time kernel (csrc/conv_wino.hip) against the direct kernel and the float64 oracle."""
