@@ -1,7 +1,8 @@
 // BiasFreeGroupNorm (no mean removal) + FiLM + exact GELU, forward and input-VJP.
 // Reference: /root/reference/networks/cqtdiff+.py:147-163 (torch.std, unbiased) and :472-482.
 //   fwd:  a = gelu( x / (std_g + eps) * gamma_c * (film_c + 1) )  =  gelu(x * scale[b][c])
-//   vjp:  du = da * gelu'(x*scale);  gx = scale*du - (x-mean_g) * S_g / ((n-1) std (std+eps)^2),
+//   vjp:  du = da * gelu'(x*scale) (formed on the fly in both passes, never stored);
+//         gx = scale*du - (x-mean_g) * S_g / ((n-1) std (std+eps)^2),
 //         S_g = sum_g( du * scale*(std+eps) * x )            
 // All of these are HBM-bound streaming kernels: float4 loads, wave-shuffle + LDS tree reductions,
 // double accumulation for the statistics.
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void scale_gelu_kernel(const float* __restrict
 }
 
 // grid: (S, B*G).  A group is cg channels of hw elements, contiguous: n = cg*hw.
-__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, float* __restrict__ dadu,
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dadu,
                                                              const float* __restrict__ scale,
                                                              double* __restrict__ part, int C, int G, long hw, int S) {
     __shared__ double sh[8];
@@ -146,7 +147,6 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
         dv.y *= gelu_grad_f(xv.y * sc);
         dv.z *= gelu_grad_f(xv.z * sc);
         dv.w *= gelu_grad_f(xv.w * sc);
-        *reinterpret_cast<float4*>(dadu + base + i) = dv;
         s0 += (double)sc * ((double)dv.x * xv.x + (double)dv.y * xv.y + (double)dv.z * xv.z + (double)dv.w * xv.w);
     }
     block_reduce2(s0, s1, sh);
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
 }
 
 // grid: (blocks, C, B)
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ du,
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ da,
                                                            const float* __restrict__ gy,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ stats,
@@ -175,11 +175,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const long base = ((long)b * C + c) * hw;
     const long nv = hw / 4;
     const float4* x4 = reinterpret_cast<const float4*>(x + base);
-    const float4* d4 = reinterpret_cast<const float4*>(du + base);
+    const float4* d4 = reinterpret_cast<const float4*>(da + base);
     const float4* g4 = gy ? reinterpret_cast<const float4*>(gy + base) : nullptr;
     float4* o4 = reinterpret_cast<float4*>(gx + base);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
-        const float4 xv = x4[i], dv = d4[i];
+        const float4 xv = x4[i];
+        float4 dv = d4[i];
+        dv.x *= gelu_grad_f(xv.x * sc);          // du, recomputed instead of round-tripping it through HBM
+        dv.y *= gelu_grad_f(xv.y * sc);
+        dv.z *= gelu_grad_f(xv.z * sc);
+        dv.w *= gelu_grad_f(xv.w * sc);
         float4 o;
         o.x = sc * dv.x - (xv.x - mean) * coef;
         o.y = sc * dv.y - (xv.y - mean) * coef;
@@ -227,25 +232,25 @@ extern "C" int babe_scale_gelu(const float* x, const float* scale, float* a, int
     return BABE_OK;
 }
 
-extern "C" int babe_gn_bwd_partial(const float* x, float* da_du, const float* scale, double* part, int B, int C,
+extern "C" int babe_gn_bwd_partial(const float* x, const float* da, const float* scale, double* part, int B, int C,
                                    int G, long hw, int S, void* stream) {
-    BABE_CHECK_ARG(x && da_du && scale && part, "gn_bwd_partial: null pointer");
+    BABE_CHECK_ARG(x && da && scale && part, "gn_bwd_partial: null pointer");
     BABE_CHECK_ARG(hw % 4 == 0 && C % G == 0, "gn_bwd_partial: hw=%ld C=%d G=%d unsupported", hw, C, G);
-    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(S, B * G), dim3(256), 0, (hipStream_t)stream, x, da_du, scale,
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(S, B * G), dim3(256), 0, (hipStream_t)stream, x, da, scale,
                        part, C, G, hw, S);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }
 
-extern "C" int babe_gn_bwd_apply(const float* x, const float* du, const float* gy, const float* scale,
+extern "C" int babe_gn_bwd_apply(const float* x, const float* da, const float* gy, const float* scale,
                                  const float* stats, const double* part, float* gx, float rbeta, int B, int C, int G,
                                  long hw, int S, float eps, void* stream) {
-    BABE_CHECK_ARG(x && du && scale && stats && part && gx, "gn_bwd_apply: null pointer");
+    BABE_CHECK_ARG(x && da && scale && stats && part && gx, "gn_bwd_apply: null pointer");
     BABE_CHECK_ARG(hw % 4 == 0 && C % G == 0, "gn_bwd_apply: hw=%ld C=%d G=%d unsupported", hw, C, G);
     int bx = cdiv(hw / 4, 256 * 4);
     if (bx < 1) bx = 1;
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, du, gy, scale, stats,
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, da, gy, scale, stats,
                        part, gx, rbeta, C, G, hw, S, eps);
     BABE_LAUNCH_CHECK();
     return BABE_OK;

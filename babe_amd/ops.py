@@ -150,7 +150,7 @@ def scale_gelu(x, scale, out):
 
 
 def gn_bwd(x, da, gy, scale, stats, gx, rbeta, G=8, eps=1e-7):
-    """da is overwritten with du; gx = rbeta*gy + GN/FiLM/GELU input-VJP (gx may alias gy)."""
+    """gx = rbeta*gy + GN/FiLM/GELU input-VJP of da (gx may alias gy; da is only read)."""
     B, Cc, F, T = x.shape
     assert x.is_contiguous() and da.is_contiguous() and gx.is_contiguous() and (gy is None or gy.is_contiguous())
     n = (Cc // G) * F * T

@@ -81,11 +81,11 @@ int babe_gn_finalize(const double* part, const float* gamma, const float* film, 
                      float eps, void* stream);
 /* a = gelu(x * scale[b][c]) */
 int babe_scale_gelu(const float* x, const float* scale, float* a, int B, int C, long hw, void* stream);
-/* VJP pass 1: du = da * gelu'(x*scale) written in place over da; part[(b*G+g)*S+s] = sum(du * scale*(std+eps) * x) */
-int babe_gn_bwd_partial(const float* x, float* da_du, const float* scale, double* part,
+/* VJP pass 1: with du = da * gelu'(x*scale) (never stored): part[(b*G+g)*S+s] = sum(du * scale*(std+eps) * x) */
+int babe_gn_bwd_partial(const float* x, const float* da, const float* scale, double* part,
                         int B, int C, int G, long hw, int S, void* stream);
-/* VJP pass 2: gx = rbeta*gy + scale*du - (x-mean)*coef_g ; coef from part and stats */
-int babe_gn_bwd_apply(const float* x, const float* du, const float* gy, const float* scale,
+/* VJP pass 2: gx = rbeta*gy + scale*du - (x-mean)*coef_g with du recomputed from da; coef from part and stats */
+int babe_gn_bwd_apply(const float* x, const float* da, const float* gy, const float* scale,
                       const float* stats, const double* part, float* gx, float rbeta,
                       int B, int C, int G, long hw, int S, float eps, void* stream);
 
