@@ -12,6 +12,7 @@ Not implemented (disabled in every blind-BWE config, conf/network/cqtdiff+.yaml:
 frequency encodings (``use_fencoding``) and time-attention layers.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -144,7 +145,48 @@ class Unet_CQT_oct_with_attention(nn.Module):
         if self._engine is None:
             sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in self.state_dict().items()}
             self._engine = UnetEngine(sd, self.Ns, self.num_dils, self.num_octs, self.bins_per_oct, self.precision)
+            self._lanes = None
         return self._engine
+
+    # Batch items are independent, so they run on separate HIP streams (one engine state each, shared packed weights):
+    # the HBM-bound passes of one item (GroupNorm / GELU / resampling, (1,1) convs) then overlap the MFMA-bound (5,3)
+    # convolutions of another, and the 1.75-round grids of the 7x64-bin layers interleave.  BABE_UNET_STREAMS=1 keeps
+    # everything on the caller's stream.
+    MAX_LANES = int(os.environ.get("BABE_UNET_STREAMS", "2"))
+
+    def _get_lanes(self, B):
+        n = min(B, self.MAX_LANES)
+        if n <= 1:
+            return None
+        if getattr(self, "_lanes", None) is None or len(self._lanes) != n:
+            eng = self.engine()
+            self._lanes = [(torch.cuda.Stream(device=self.device), eng if i == 0 else eng.clone_state()) for i in range(n)]
+        return self._lanes
+
+    def _run_lanes(self, B, fn):
+        """fn(engine, b0, b1) -> list of tensors for batch rows [b0, b1); rows are dealt to the lanes in contiguous blocks.
+        Returns the per-lane results after making the caller's stream wait for every lane."""
+        lanes = self._get_lanes(B)
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        per = -(-B // len(lanes))
+        results = []
+        for i, (st, eng) in enumerate(lanes):
+            b0, b1 = i * per, min(B, (i + 1) * per)
+            if b0 >= b1:
+                continue
+            with torch.cuda.stream(st):
+                st.wait_event(ready)
+                out = fn(eng, b0, b1)
+                for t in out:
+                    t.record_stream(main)              # consumed on the caller's stream after the join below
+                done = torch.cuda.Event()
+                done.record(st)
+            results.append((out, done))
+        for _, done in results:
+            main.wait_event(done)
+        return [r for r, _ in results]
 
     def _apply(self, fn, *a, **k):
         self._engine = None
@@ -158,14 +200,24 @@ class Unet_CQT_oct_with_attention(nn.Module):
         assert x.shape[-1] == self.CQTransform.Ls, "input length must equal exp.audio_len (the CQT is built for it)"
         film = eng.embed(cnoise.detach().reshape(-1, 1).contiguous().float())
         co = self.CQTransform.fwd_planar(x)
-        outs = eng.forward(co, film)
+        B = x.shape[0]
+        if self._get_lanes(B) is None:
+            outs = eng.forward(co, film)
+        else:
+            parts = self._run_lanes(B, lambda e, b0, b1: e.forward([c[b0:b1] for c in co], film[b0:b1]))
+            outs = [torch.cat([p[j] for p in parts], 0) for j in range(len(co))]
         return self.CQTransform.bwd_planar(outs)
 
     def vjp(self, g):
         """Gradient of <net(x), g> w.r.t. x for the last fwd_nograd call."""
         eng = self.engine()
         gouts = self.CQTransform.bwd_adjoint(g.contiguous())
-        gC = eng.vjp(gouts)
+        B = g.shape[0]
+        if self._get_lanes(B) is None:
+            gC = eng.vjp(gouts)
+        else:
+            parts = self._run_lanes(B, lambda e, b0, b1: e.vjp([c[b0:b1] for c in gouts]))
+            gC = [torch.cat([p[j] for p in parts], 0) for j in range(len(gouts))]
         return self.CQTransform.fwd_adjoint(gC)
 
     # ---------------------------------------------------------------- nn.Module call

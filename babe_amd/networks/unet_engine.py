@@ -91,6 +91,17 @@ class UnetEngine:
         self.film_idx = fi
         self._scratch = {}
 
+    def clone_state(self):
+        """A second engine over the SAME packed weights with its own per-call state (saved activations, scratch), so that
+        two batch items can run on two streams at once."""
+        import copy
+        c = copy.copy(self)
+        c._scratch = {}
+        cp = lambda blks: [copy.copy(b) for b in blks]
+        c.init_blk, c.main_blk, c.up_out, c.up_blk = cp(self.init_blk), cp(self.main_blk), cp(self.up_out), cp(self.up_blk)
+        c.mid_blk, c.mid_out = copy.copy(self.mid_blk), copy.copy(self.mid_out)
+        return c
+
     # ------------------------------------------------------------------ helpers
     def buf(self, *shape):
         return torch.empty(*shape, device=self.dev, dtype=torch.float32)
