@@ -236,3 +236,27 @@ def test_unet_other_geometries_vs_oracle(fs, L, B):
     gx, = torch.autograd.grad((y * wv.cuda()).sum(), xg)
     assert rel(y, yref) < 5e-5
     assert rel(gx, gref) < 5e-4
+
+
+def test_unet_stream_lanes_equal_single_stream():
+    """Batch items on separate HIP streams (Unet_CQT_oct_with_attention.MAX_LANES) give bit-identical forward and VJP."""
+    from babe_amd.config import default_args
+    from babe_amd.networks.cqtdiff_plus import Unet_CQT_oct_with_attention, init_state_dict
+    Ns = [16, 16, 16, 16, 32, 32, 32]
+    args = default_args(sample_rate=22050, audio_len=92092, Ns=Ns, T=3)
+    net = Unet_CQT_oct_with_attention(args, "cuda")
+    net.load_state_dict(init_state_dict(Ns, args.network.num_dils, seed=0, gate_scale=1.0))
+    g = torch.Generator().manual_seed(0)
+    x = (0.1 * torch.randn(3, 92092, generator=g)).cuda()
+    cn = torch.tensor([[-0.4], [-1.0], [0.3]]).cuda()
+    gy = torch.randn(3, 92092, generator=g).cuda()
+    ref = None
+    for lanes in (1, 2, 3, 2):
+        net.MAX_LANES = lanes
+        y = net.fwd_nograd(x, cn)
+        gx = net.vjp(gy)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (y.clone(), gx.clone())
+        else:
+            assert torch.equal(y, ref[0]) and torch.equal(gx, ref[1]), f"lanes={lanes}"
