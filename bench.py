@@ -98,7 +98,8 @@ def conv_traffic(precision):
     with open(path) as f:
         t = json.load(f)
     return {"bytes_per_launch": round(t["bytes_per_launch"]), "fetch": round(t["fetch_bytes_per_launch"]),
-            "write": round(t["write_bytes_per_launch"]), "source": "profiles/r01_conv_traffic.json (PMC passes, not live)"}
+            "write": round(t["write_bytes_per_launch"]), "unit": "bytes per launch",
+            "source": "profiles/r01_conv_traffic.json (PMC passes, not live)"}
 
 
 def main():
@@ -234,9 +235,10 @@ def main():
                  "conv_bf16_kernel (v_mfma_f32_32x32x16_bf16; %s products per k-block; achieved counts ALGORITHMIC flops)"
                  % ("3" if a.precision == "bf16x3" else "1"))
         if a.profile_convs and ms.value > 0:
+            tr = conv_traffic(a.precision)
             ach = fl.value / (ms.value * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": conv_traffic(a.precision),
+                    "frac": round(ach / peak, 4), "traffic": (tr or {}).get("bytes_per_launch"), "traffic_detail": tr,
                     "kernel": kname,
                     "launches": nl.value, "avg_launch_us": round(ms.value * 1e3 / max(nl.value, 1), 2),
                     "algorithmic_tflop_per_launch_avg": round(fl.value / max(nl.value, 1) / 1e12, 5),
