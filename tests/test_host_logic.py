@@ -162,3 +162,28 @@ def test_long_file_AR_driver_sequence():
     assert torch.equal(out[last:last + 250], y[last + 200:last + 450])
     assert f.calls[0][0] == "bwe" and all(c[0] == "ar" for c in f.calls[1:]) and len(f.calls) >= 3
     assert f.calls[1][1] == 250                      # 0.25 s overlap at 1 kHz is the known region
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The newest bench line under profiles/ carries every field the driver / judge reads (format regression guard)."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r01_bench_v[0-9]*.json")),
+                   key=lambda p: int("".join(ch for ch in os.path.basename(p).split("_v")[1].split(".")[0].split("_")[0] if ch.isdigit())))
+    headline = [f for f in files if os.path.basename(f).count("_") == 2]          # r01_bench_vN.json (no suffix)
+    d = json.loads(open(headline[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "audio-sec/s" and d["dtype"] == "f32" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["headline"] is True
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or isinstance(r["traffic"], (int, float))
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] >= 1
