@@ -75,15 +75,45 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = sig
             fn.restype = C.c_int
-        _extra_sigs(L)
+        L.babe_prof_nslots.restype = C.c_int
+        L.babe_prof_slot_name.restype = C.c_char_p
+        L.babe_prof_slot_name.argtypes = [_I]
+        L.babe_prof_enable.argtypes = [_I]
+        L.babe_prof_conv_slot.argtypes = [_I]
+        L.babe_prof_read.argtypes = [_P, _P, _P, _P, _P]
+        L.babe_prof_dispatch_counts.argtypes = [_P, _I]
         _lib = L
     return _lib
 
 
-def _extra_sigs(L):
-    """Signatures of the CQT / STFT / sampler entry points (registered if present)."""
-    from . import _sigs_extra
-    _sigs_extra.register(L)
+def prof_slot_names():
+    L = lib()
+    return [L.babe_prof_slot_name(i).decode() for i in range(L.babe_prof_nslots())]
+
+
+def prof_enable(on):
+    """Measurement hook (include/babe_hip.h): HIP-event timing of every launch, tallied per kernel slot."""
+    lib().babe_prof_enable(int(bool(on)))
+
+
+def prof_read():
+    """{slot name: dict(ms, bytes, flops, exec_flops, launches)} since the last read (waits for the GPU); resets."""
+    L = lib()
+    n = L.babe_prof_nslots()
+    D, Lg = (C.c_double * n), (C.c_long * n)
+    ms, by, fl, ex, nl = D(), D(), D(), D(), Lg()
+    check(L.babe_prof_read(ms, by, fl, ex, nl), "prof_read")
+    return {name: dict(ms=ms[i], bytes=by[i], flops=fl[i], exec_flops=ex[i], launches=nl[i])
+            for i, name in enumerate(prof_slot_names())}
+
+
+def dispatch_counts(reset=False):
+    """Always-on launch counters per slot: which kernel each conv call really took (wino4 / wino2 / direct / bf16)."""
+    L = lib()
+    n = L.babe_prof_nslots()
+    cnt = (C.c_long * n)()
+    L.babe_prof_dispatch_counts(cnt, int(reset))
+    return {name: cnt[i] for i, name in enumerate(prof_slot_names())}
 
 
 def check(rc, what=""):
@@ -98,5 +128,10 @@ def ptr(t):
     return t.data_ptr()
 
 
-def stream():
-    return torch.cuda.current_stream().cuda_stream
+def stream(t=None):
+    """HIP stream the next launch goes to: the current stream OF THE DEVICE the operands live on (`t`: a tensor or a
+    torch.device).  The library never calls hipSetDevice; launching device-1 pointers on device 0's stream faults, so
+    multi-device hosts must either pass `t` or run under torch.cuda.device(...) as the network/sampler entry points do."""
+    if t is None:
+        return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(t.device if torch.is_tensor(t) else t).cuda_stream

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libbabe_hip.so")
-SOURCES = ["misc.hip", "conv.hip", "conv_bf16.hip", "conv_wino.hip", "conv_wino4.hip", "norm.hip", "resample.hip", "fft.hip", "cqt.hip", "stft.hip", "sampler.hip", "denoiser.hip"]
+SOURCES = ["misc.hip", "conv.hip", "conv_bf16.hip", "conv_wino.hip", "conv_wino4.hip", "norm.hip", "resample.hip", "cqt.hip", "stft.hip", "sampler.hip", "denoiser.hip"]
 
 
 def needs_build():
@@ -39,15 +39,16 @@ def _build_locked(force, verbose):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    hdr_mtime = max([os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h")] +
+                    [os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "babe_hip.h"))])
     for src in SOURCES:
         p = os.path.join(CSRC, src)
         if not os.path.exists(p):
-            continue
+            raise FileNotFoundError(f"{p}: listed in babe_amd/build.py SOURCES but missing")
         o = os.path.join(HERE, "build", src + ".o")
         objs.append(o)
-        if (not force) and os.path.exists(o) and os.path.getmtime(o) > max(
-                os.path.getmtime(p), os.path.getmtime(os.path.join(CSRC, "common.h")),
-                os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "babe_hip.h"))):
+        # every object depends on its source, on every header in csrc/ and on the public header
+        if (not force) and os.path.exists(o) and os.path.getmtime(o) > max([os.path.getmtime(p), hdr_mtime]):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", p, "-o", o,
                "-Wno-unused-result"]

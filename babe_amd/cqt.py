@@ -108,11 +108,15 @@ def factor_len(L):
     return N1, N2
 
 
+DFT_SLOT = 5        # BABE_SLOT_DFT_STAGE (csrc/prof.h)
+
+
 class _BandsStruct(C.Structure):
     _fields_ = [("nbands", C.c_int), ("L", C.c_int), ("KX", C.c_int),
                 ("c", C.c_void_p), ("M", C.c_void_p), ("woff", C.c_void_p), ("log2T", C.c_void_p),
                 ("oct", C.c_void_p), ("binoct", C.c_void_p), ("tw4096", C.c_void_p),
-                ("nocts", C.c_int), ("binsoct", C.c_int), ("coef", C.c_void_p * 8)]
+                ("nocts", C.c_int), ("binsoct", C.c_int), ("coef", C.c_void_p * 8),
+                ("sum_T", C.c_long), ("sum_M", C.c_long), ("sum_TlogT", C.c_double)]
 
 
 def _register_sigs():
@@ -158,20 +162,20 @@ class RealFFT:
 
     def rfft(self, x, out=None):
         """x [B,L] -> planar spectrum [B,2,KX] (bins above L/2 hold valid but redundant values)."""
-        lib().babe_conv_prof_pause(1)
+        lib().babe_prof_conv_slot(DFT_SLOT)
         try:
             return self._rfft(x, out)
         finally:
-            lib().babe_conv_prof_pause(0)
+            lib().babe_prof_conv_slot(-1)
 
     def rfft_T(self, spec, out=None):
         """Transpose (real-linear adjoint) of rfft: planar [B,2,KX] (entries above L/2 must be 0) -> [B,L].
         irfft(X) = rfft_T(c*X/L) with c = 1 at DC/Nyquist and 2 elsewhere."""
-        lib().babe_conv_prof_pause(1)
+        lib().babe_prof_conv_slot(DFT_SLOT)
         try:
             return self._rfft_T(spec, out)
         finally:
-            lib().babe_conv_prof_pause(0)
+            lib().babe_prof_conv_slot(-1)
 
     def _rfft(self, x, out=None):
         B = x.shape[0]
@@ -248,6 +252,8 @@ class CQT_nsgt:
             setattr(s, k, ptr(self._tabs[k]))
         s.tw4096 = ptr(self.tw4096)
         s.nocts, s.binsoct = self.numocts, self.binsoct
+        s.sum_T, s.sum_M = int(np.sum(d["T"])), int(np.sum(d["M"]))
+        s.sum_TlogT = float(np.sum(d["T"] * np.log2(d["T"])))
         for j, cf in enumerate(coefs):
             assert cf.is_contiguous() and cf.shape[1:] == (2, self.binsoct, self.T_oct[j]), cf.shape
             s.coef[j] = ptr(cf)

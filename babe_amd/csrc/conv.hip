@@ -14,6 +14,7 @@
 // per step.  Zero "same" padding is applied at staging time.
 #include "common.h"
 #include "../../include/babe_hip.h"
+#include "prof.h"
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -418,65 +419,6 @@ int launch_conv(const babe_conv_args& a, ConvGeom g, hipStream_t s) {
 
 }  // namespace
 
-// ---- optional per-launch timing of the conv kernel (bench.py roofline): HIP events on the launch stream
-#include <vector>
-namespace {
-struct ConvProf {
-    bool on = false;
-    bool paused = false;
-    std::vector<hipEvent_t> ev;      // pairs (start, stop)
-    size_t used = 0;
-    double flops = 0;
-} g_prof;
-}  // namespace
-
-extern "C" int babe_conv_prof_enable(int on) {
-    g_prof.on = on != 0;
-    g_prof.used = 0;
-    g_prof.flops = 0;
-    return BABE_OK;
-}
-
-extern "C" int babe_conv_prof_pause(int paused) {
-    g_prof.paused = paused != 0;
-    return BABE_OK;
-}
-
-extern "C" int babe_conv_prof_read(double* ms_total, double* flops_total, long* launches) {
-    double ms = 0;
-    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-        if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) {
-            babe_set_error("conv_prof_read: hipEventSynchronize failed");
-            return BABE_ERR_HIP;
-        }
-        float t = 0;
-        hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
-        ms += t;
-    }
-    if (ms_total) *ms_total = ms;
-    if (flops_total) *flops_total = g_prof.flops;
-    if (launches) *launches = (long)(g_prof.used / 2);
-    g_prof.used = 0;
-    g_prof.flops = 0;
-    return BABE_OK;
-}
-
-static hipEvent_t prof_event() {
-    if (g_prof.used == g_prof.ev.size()) {
-        hipEvent_t e;
-        hipEventCreate(&e);
-        g_prof.ev.push_back(e);
-    }
-    return g_prof.ev[g_prof.used++];
-}
-
-// shared with conv_bf16.hip
-extern "C" void babe_conv_prof_mark(int begin, double flops, void* stream) {
-    if (!(g_prof.on && !g_prof.paused)) return;
-    hipEventRecord(prof_event(), (hipStream_t)stream);
-    if (begin) g_prof.flops += flops;
-}
-
 extern "C" long babe_conv_packed_size(int Cout, int Cin, int KH, int KW, int transpose_flip) {
     const int co = transpose_flip ? Cin : Cout;
     const int ci = transpose_flip ? Cout : Cin;
@@ -521,16 +463,8 @@ extern "C" int babe_conv2d(const babe_conv_args* ap, void* stream) {
         if (ov && ov[0] == '2') wp2 = true;
     }
     hipStream_t s = (hipStream_t)stream;
-    const bool prof = g_prof.on && !g_prof.paused;
-    if (prof) {
-        hipEventRecord(prof_event(), s);
-        g_prof.flops += 2.0 * a.B * (double)a.Cout * a.Cin * a.KH * a.KW * (double)a.F * a.T;
-    }
-    struct ProfStop {
-        hipStream_t s;
-        bool on;
-        ~ProfStop() { if (on) hipEventRecord(prof_event(), s); }
-    } prof_stop{s, prof};
+    const double flops = babe_conv_flops(a);
+    BabeProfScope prof(a.KH > 1 ? BABE_SLOT_CONV53_DIRECT : BABE_SLOT_CONV11, babe_conv_bytes(a), flops, flops, stream);
     // vector staging needs 16-byte aligned rows in every source tensor
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     bool vec = (a.T % 4 == 0) && al16(a.in) && (a.in_bs % 4 == 0) && (a.in_cs % 4 == 0) &&

@@ -9,6 +9,7 @@
 // which is exactly one MFMA operand fragment: A = weights [k-group h][co], B = activations [k-group h][pos].
 #include "common.h"
 #include "../../include/babe_hip.h"
+#include "prof.h"
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -356,7 +357,6 @@ extern "C" int babe_conv_pack_weights_bf16(const float* w, void* dst, int Cout, 
     return BABE_OK;
 }
 
-extern "C" void babe_conv_prof_mark(int begin, double flops, void* stream);   // conv.hip
 
 extern "C" int babe_conv2d_bf16(const babe_conv_args* ap, const void* w_bf16, int splits, void* stream) {
     BABE_CHECK_ARG(ap && w_bf16, "conv2d_bf16: null args");
@@ -382,11 +382,8 @@ extern "C" int babe_conv2d_bf16(const babe_conv_args* ap, const void* w_bf16, in
     }
     hipStream_t s = (hipStream_t)stream;
     const unsigned short* wq = (const unsigned short*)w_bf16;
-    babe_conv_prof_mark(1, 2.0 * a.B * (double)a.Cout * a.Cin * a.KH * a.KW * (double)a.F * a.T, stream);
-    struct ProfStop {
-        void* s;
-        ~ProfStop() { babe_conv_prof_mark(0, 0, s); }
-    } prof_stop{stream};
+    const double flops = babe_conv_flops(a);
+    BabeProfScope prof(BABE_SLOT_CONV_BF16, babe_conv_bytes(a), flops, flops * (splits == 2 ? 3 : 1), stream);
 #define BC(NTv, WPv)                                                              \
     if (a.KW == 3) {                                                              \
         if (splits == 2) launch<NTv, WPv, 3, 2>(a, g, wq, s);                     \

@@ -15,6 +15,7 @@
 // one 16-byte read gives a lane all 4 phases of its B (resp. A) operand.
 #include "common.h"
 #include "../../include/babe_hip.h"
+#include "prof.h"
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -576,7 +577,6 @@ void launch_pp(const babe_conv_args& a, WinoGeom g, const float* wq, hipStream_t
 
 }  // namespace
 
-extern "C" void babe_conv_prof_mark(int begin, double flops, void* stream);   // conv.hip
 
 extern "C" long babe_conv_packed_size_wino(int Cout, int Cin, int KH, int transpose_flip) {
     const int co = transpose_flip ? Cin : Cout;
@@ -621,12 +621,12 @@ extern "C" int babe_conv2d_wino(const babe_conv_args* ap, const float* w_wino, v
     g.CoutP = (a.Cout + 31) / 32 * 32;
     const int n32 = g.CoutP / 32;
     hipStream_t s = (hipStream_t)stream;
-    babe_conv_prof_mark(1, 2.0 * a.B * (double)a.Cout * a.Cin * a.KH * a.KW * (double)a.F * a.T, stream);
+    const double flops = babe_conv_flops(a);     // F(2,3): 4 multiplies per 2 outputs instead of 6
+    BabeProfScope prof(BABE_SLOT_CONV53_WINO2, babe_conv_bytes(a), flops, flops * (2.0 / 3.0), stream);
     if (n32 == 1) launch<1, 1, 4>(a, g, w_wino, s);            //  32 co x 256 positions
     else if (wino_use_pp(n32)) launch_pp<3, 2>(a, g, w_wino, s);   //  96 co x 128 positions, phase-pair split
     else if (n32 == 2) launch<2, 1, 4>(a, g, w_wino, s);       //  64 co x 256 positions
     else launch<2, 2, 2>(a, g, w_wino, s);                     // 128 co x 128 positions
-    babe_conv_prof_mark(0, 0, stream);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

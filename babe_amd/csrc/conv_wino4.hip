@@ -24,6 +24,7 @@
 // staging removed the loop runs at 234, i.e. the activation staging is what is left to hide.
 #include "common.h"
 #include "../../include/babe_hip.h"
+#include "prof.h"
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -333,7 +334,6 @@ void launch4(const babe_conv_args& a, Wino4Geom g, const float* wq, hipStream_t 
 
 }  // namespace
 
-extern "C" void babe_conv_prof_mark(int begin, double flops, void* stream);   // conv.hip
 
 extern "C" long babe_conv_packed_size_wino4(int Cout, int Cin, int KH, int transpose_flip) {
     const int co = transpose_flip ? Cin : Cout;
@@ -377,11 +377,11 @@ extern "C" int babe_conv2d_wino4(const babe_conv_args* ap, const float* w_wino4,
     g.CoutP = (a.Cout + 31) / 32 * 32;
     const int n32 = g.CoutP / 32;
     hipStream_t s = (hipStream_t)stream;
-    babe_conv_prof_mark(1, 2.0 * a.B * (double)a.Cout * a.Cin * a.KH * a.KW * (double)a.F * a.T, stream);
+    const double flops = babe_conv_flops(a);     // F(4,3): 6 multiplies per 4 outputs instead of 12
+    BabeProfScope prof(BABE_SLOT_CONV53_WINO4, babe_conv_bytes(a), flops, flops * 0.5, stream);
     if (n32 == 2) launch4<2, 1, 2>(a, g, w_wino4, s);            //  64 co x 256 positions, 4 waves
     else if (n32 == 3) launch4<3, 1, 2>(a, g, w_wino4, s);       //  96 co x 256 positions, 4 waves
     else launch4<2, 2, 2>(a, g, w_wino4, s);                     // 128 co x 256 positions, 8 waves
-    babe_conv_prof_mark(0, 0, stream);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

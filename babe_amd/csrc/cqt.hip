@@ -5,6 +5,7 @@
 #include "common.h"
 #include "fft_lds.h"
 #include "../../include/babe_hip.h"
+#include "prof.h"
 
 namespace {
 
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(256) void twiddle_transpose_kernel(const float* __r
 extern "C" int babe_fft_twiddle_transpose(const float* in, float* out, const float* tw, int B, int N1, int N2,
                                           int adjoint, void* stream) {
     BABE_CHECK_ARG(in && out && tw && B > 0 && N1 > 0 && N2 > 0, "fft_twiddle_transpose: bad arguments");
+    BabeProfScope prof(BABE_SLOT_CQT_GATHER, 24.0 * B * (double)N1 * N2, 0, 0, stream);
     hipLaunchKernelGGL(twiddle_transpose_kernel, dim3(cdiv(N2, 32), cdiv(N1, 32), B), dim3(256), 0,
                        (hipStream_t)stream, in, out, reinterpret_cast<const float2*>(tw), N1, N2, adjoint);
     BABE_LAUNCH_CHECK();
@@ -197,6 +199,7 @@ extern "C" int babe_cqt_band_analysis(const babe_cqt_bands* bd, const float* spe
                                       void* stream) {
     if (check_bands(bd)) return BABE_ERR_ARG;
     BABE_CHECK_ARG(spec && win && B > 0, "cqt_band_analysis: bad arguments");
+    BabeProfScope prof(BABE_SLOT_CQT_ANALYSIS, (double)B * (8.0 * (bd->L / 2 + 1) + 8.0 * bd->sum_T + 4.0 * bd->sum_M), 5.0 * B * bd->sum_TlogT, 0, stream);
     hipLaunchKernelGGL(band_analysis_kernel, dim3(bd->nbands, B), dim3(512), 0, (hipStream_t)stream, *bd, spec, win);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
@@ -206,6 +209,7 @@ extern "C" int babe_cqt_band_synthesis(const babe_cqt_bands* bd, float* bs, cons
                                        void* stream) {
     if (check_bands(bd)) return BABE_ERR_ARG;
     BABE_CHECK_ARG(bs && win && B > 0, "cqt_band_synthesis: bad arguments");
+    BabeProfScope prof(BABE_SLOT_CQT_SYNTHESIS, (double)B * (8.0 * bd->sum_T + 12.0 * bd->sum_M), 5.0 * B * bd->sum_TlogT, 0, stream);
     hipLaunchKernelGGL(band_synthesis_kernel, dim3(bd->nbands, B), dim3(512), 0, (hipStream_t)stream, *bd, bs, win,
                        bs_stride);
     BABE_LAUNCH_CHECK();
@@ -215,6 +219,7 @@ extern "C" int babe_cqt_band_synthesis(const babe_cqt_bands* bd, float* bs, cons
 extern "C" int babe_cqt_gather(const float* bs, long bs_stride, const int* rowptr, const int* src, float* spec, int KX,
                                int L, float scale, const float* mul, int B, void* stream) {
     BABE_CHECK_ARG(bs && rowptr && src && spec && KX > L / 2 && B > 0, "cqt_gather: bad arguments");
+    BabeProfScope prof(BABE_SLOT_CQT_GATHER, (double)B * 8.0 * (bs_stride + KX), 0, 0, stream);
     hipLaunchKernelGGL(gather_kernel, dim3(cdiv(KX, 256), B), dim3(256), 0, (hipStream_t)stream, bs, bs_stride, rowptr,
                        src, spec, KX, L, scale, mul);
     BABE_LAUNCH_CHECK();
@@ -224,6 +229,7 @@ extern "C" int babe_cqt_gather(const float* bs, long bs_stride, const int* rowpt
 extern "C" int babe_spec_scale(const float* s1, const float* s2, float* out, const float* mul, int KX, int L,
                                float sc1, float sc2, int B, void* stream) {
     BABE_CHECK_ARG(s1 && out && KX > L / 2 && B > 0, "spec_scale: bad arguments");
+    BabeProfScope prof(BABE_SLOT_CQT_GATHER, (double)B * 8.0 * KX * (s2 ? 3 : 2), 0, 0, stream);
     hipLaunchKernelGGL(spec_scale_kernel, dim3(cdiv(KX, 256), B), dim3(256), 0, (hipStream_t)stream, s1, s2, out, mul,
                        KX, L, sc1, sc2);
     BABE_LAUNCH_CHECK();

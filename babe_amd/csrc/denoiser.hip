@@ -11,6 +11,7 @@
 //   weights [KH'][KW][8][64] follow in slabs of KH' kernel rows.
 #include "common.h"
 #include "../../include/babe_hip.h"
+#include "prof.h"
 #include "fft_lds.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -393,6 +394,9 @@ extern "C" int babe_dn_conv2d(const babe_dnconv_args* ap, const float* w_packed,
     BABE_CHECK_ARG(a.ksplit <= 1 || a.ws, "dn_conv2d: ksplit=%d needs a workspace of ksplit*B*Cout*OH*OW floats", a.ksplit);
     BABE_CHECK_ARG((double)a.in_cs * a.Cin < 4.0e9, "dn_conv2d: one batch item of the input must stay below 2^32 elements");
     hipStream_t s = (hipStream_t)stream;
+    const double dn_flops = 2.0 * a.B * (double)a.Cout * a.Cin * a.KH * a.KW * (double)a.OH * a.OW;
+    BabeProfScope prof(BABE_SLOT_DENOISER, 4.0 * a.B * ((double)a.Cin * a.IH * a.IW + (double)a.Cout * a.OH * a.OW),
+                       dn_flops, dn_flops, stream);
     const int key = a.KH * 100 + a.KW * 10 + a.stride;
     switch (key) {
         case 331: dn_launch<3, 3, 1, 3, 8>(a, w_packed, s); break;

@@ -1,7 +1,9 @@
 // Small helpers: library info / errors, strided axpby (cat / slice / residual merges), Linear, RFF.
 #include "common.h"
 #include "../../include/babe_hip.h"
+#include "prof.h"
 #include <cstdarg>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -13,6 +15,95 @@ void babe_set_error(const char* fmt, ...) {
 }
 extern "C" const char* babe_last_error(void) { return g_err; }
 extern "C" const char* babe_version(void) { return "babe_hip 0.1 (gfx950)"; }
+
+// ---- measurement hook (prof.h) ---------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t e0, e1; int slot; };
+struct Prof {
+    bool on = false;
+    int conv_slot_override = -1;          // >= 0: conv launches are tallied there (the DFT stages of the CQT)
+    std::vector<ProfRec> rec;
+    size_t used = 0;
+    double bytes[BABE_NSLOTS] = {}, flops[BABE_NSLOTS] = {}, exec[BABE_NSLOTS] = {};
+    long dispatch[BABE_NSLOTS] = {};      // always-on launch counters
+    bool open = false;
+} g_prof;
+const char* const kSlotNames[BABE_NSLOTS] = {
+    "conv53_wino4", "conv53_wino2", "conv53_direct", "conv11", "conv_bf16", "dft_stage", "gn_stats", "scale_gelu",
+    "gn_bwd_partial", "gn_bwd_apply", "resample", "axpby", "film", "cqt_band_analysis", "cqt_band_synthesis",
+    "cqt_gather", "stft_fwd", "istft", "mag_stats", "filter_fit", "sampler", "denoiser"};
+}  // namespace
+
+extern "C" void babe_prof_begin(int slot, double bytes, double flops, double exec_flops, void* stream) {
+    if (slot <= BABE_SLOT_CONV_BF16 && g_prof.conv_slot_override >= 0) slot = g_prof.conv_slot_override;
+    g_prof.dispatch[slot]++;
+    if (!g_prof.on) return;
+    if (g_prof.used == g_prof.rec.size()) {
+        ProfRec r;
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
+        g_prof.rec.push_back(r);
+    }
+    ProfRec& r = g_prof.rec[g_prof.used];
+    r.slot = slot;
+    (void)hipEventRecord(r.e0, (hipStream_t)stream);
+    g_prof.bytes[slot] += bytes;
+    g_prof.flops[slot] += flops;
+    g_prof.exec[slot] += exec_flops;
+    g_prof.open = true;
+}
+extern "C" void babe_prof_end(void* stream) {
+    if (!g_prof.open) return;
+    (void)hipEventRecord(g_prof.rec[g_prof.used++].e1, (hipStream_t)stream);
+    g_prof.open = false;
+}
+extern "C" int babe_prof_nslots(void) { return BABE_NSLOTS; }
+extern "C" const char* babe_prof_slot_name(int slot) { return (slot >= 0 && slot < BABE_NSLOTS) ? kSlotNames[slot] : ""; }
+extern "C" int babe_prof_enable(int on) {
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    g_prof.open = false;
+    for (int i = 0; i < BABE_NSLOTS; ++i) g_prof.bytes[i] = g_prof.flops[i] = g_prof.exec[i] = 0;
+    return BABE_OK;
+}
+extern "C" int babe_prof_conv_slot(int slot) {
+    g_prof.conv_slot_override = (slot >= 0 && slot < BABE_NSLOTS) ? slot : -1;
+    return BABE_OK;
+}
+/* ms/bytes/flops/exec_flops/launches: arrays of babe_prof_nslots() entries; waits for the recorded events; resets. */
+extern "C" int babe_prof_read(double* ms, double* bytes, double* flops, double* exec_flops, long* launches) {
+    for (int i = 0; i < BABE_NSLOTS; ++i) {
+        if (ms) ms[i] = 0;
+        if (launches) launches[i] = 0;
+    }
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        ProfRec& r = g_prof.rec[i];
+        if (hipEventSynchronize(r.e1) != hipSuccess) {
+            babe_set_error("prof_read: hipEventSynchronize failed");
+            return BABE_ERR_HIP;
+        }
+        float t = 0;
+        (void)hipEventElapsedTime(&t, r.e0, r.e1);
+        if (ms) ms[r.slot] += t;
+        if (launches) launches[r.slot]++;
+    }
+    for (int i = 0; i < BABE_NSLOTS; ++i) {
+        if (bytes) bytes[i] = g_prof.bytes[i];
+        if (flops) flops[i] = g_prof.flops[i];
+        if (exec_flops) exec_flops[i] = g_prof.exec[i];
+        g_prof.bytes[i] = g_prof.flops[i] = g_prof.exec[i] = 0;
+    }
+    g_prof.used = 0;
+    return BABE_OK;
+}
+/* always-on launch counters per slot (which kernel a conv call really dispatched to); reset != 0 clears them */
+extern "C" int babe_prof_dispatch_counts(long* counts, int reset) {
+    for (int i = 0; i < BABE_NSLOTS; ++i) {
+        if (counts) counts[i] = g_prof.dispatch[i];
+        if (reset) g_prof.dispatch[i] = 0;
+    }
+    return BABE_OK;
+}
 
 namespace {
 // y = alpha*x + beta*y over [B][C] planes of n = F*T contiguous floats (rows are contiguous, so a frequency sub-view
@@ -77,7 +168,7 @@ extern "C" int babe_axpby4d(const float* in, long in_bs, long in_cs, float* out,
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     const bool v4 = (n % 4 == 0) && al16(in) && al16(out) && in_bs % 4 == 0 && in_cs % 4 == 0 && out_bs % 4 == 0 &&
                     out_cs % 4 == 0;
-    BABE_CHECK_ARG((long)B * C <= 65535, "axpby4d: grid too large");
+    BabeProfScope prof(BABE_SLOT_AXPBY, (beta != 0.f ? 12.0 : 8.0) * B * C * (double)n, 0, 0, stream);
     if (v4) {
         int bx = cdiv(n / 4, 256);
         if (bx > 64) bx = 64;
@@ -96,6 +187,7 @@ extern "C" int babe_axpby4d(const float* in, long in_bs, long in_cs, float* out,
 extern "C" int babe_linear(const float* x, const float* W, const float* bias, float* out, int B, int K, int J,
                            int relu, void* stream) {
     BABE_CHECK_ARG(x && W && out && B > 0 && K > 0 && J > 0, "linear: bad arguments");
+    BabeProfScope prof(BABE_SLOT_FILM, 4.0 * ((double)J * K + (double)B * (K + J)), 2.0 * B * J * K, 0, stream);
     hipLaunchKernelGGL(linear_kernel, dim3(cdiv(J, 4)), dim3(256), 0, (hipStream_t)stream, x, W, bias, out, B, K, J,
                        relu);
     BABE_LAUNCH_CHECK();
@@ -104,6 +196,7 @@ extern "C" int babe_linear(const float* x, const float* W, const float* bias, fl
 
 extern "C" int babe_rff(const float* cnoise, const float* freq, float* out, int B, int R, void* stream) {
     BABE_CHECK_ARG(cnoise && freq && out && B > 0 && R > 0, "rff: bad arguments");
+    BabeProfScope prof(BABE_SLOT_FILM, 4.0 * B * (1 + 3 * R), 0, 0, stream);
     hipLaunchKernelGGL(rff_kernel, dim3(cdiv(B * R, 64)), dim3(64), 0, (hipStream_t)stream, cnoise, freq, out, B, R);
     BABE_LAUNCH_CHECK();
     return BABE_OK;

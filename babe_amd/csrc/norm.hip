@@ -8,6 +8,7 @@
 // double accumulation for the statistics.
 #include "common.h"
 #include "../../include/babe_hip.h"
+#include "prof.h"
 
 namespace {
 
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 extern "C" int babe_gn_partial(const float* x, double* part, int B, int G, long n, int S, void* stream) {
     BABE_CHECK_ARG(x && part && B > 0 && G > 0 && n > 1 && S > 0, "gn_partial: bad arguments");
     BABE_CHECK_ARG(n % 4 == 0, "gn_partial: group size %ld not a multiple of 4", n);
+    BabeProfScope prof(BABE_SLOT_GN_STATS, 4.0 * B * G * (double)n, 0, 0, stream);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(S, B * G), dim3(256), 0, (hipStream_t)stream, x, part, n, S);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
@@ -215,6 +217,7 @@ extern "C" int babe_gn_finalize(const double* part, const float* gamma, const fl
                                 float* scale, int B, int C, int G, long n, int S, float eps, void* stream) {
     BABE_CHECK_ARG(part && gamma && film && stats && scale, "gn_finalize: null pointer");
     BABE_CHECK_ARG(G <= 64 && C % G == 0, "gn_finalize: C=%d G=%d unsupported", C, G);
+    BabeProfScope prof(BABE_SLOT_GN_STATS, 0, 0, 0, stream);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, part, gamma, film, film_bs,
                        stats, scale, C, G, n, S, eps);
     BABE_LAUNCH_CHECK();
@@ -224,6 +227,7 @@ extern "C" int babe_gn_finalize(const double* part, const float* gamma, const fl
 extern "C" int babe_scale_gelu(const float* x, const float* scale, float* a, int B, int C, long hw, void* stream) {
     BABE_CHECK_ARG(x && scale && a && B > 0 && C > 0 && hw > 0, "scale_gelu: bad arguments");
     BABE_CHECK_ARG(hw % 4 == 0, "scale_gelu: plane size %ld not a multiple of 4", hw);
+    BabeProfScope prof(BABE_SLOT_SCALE_GELU, 8.0 * B * C * (double)hw, 0, 0, stream);
     int bx = cdiv(hw / 4, 256 * 4);
     if (bx < 1) bx = 1;
     if (bx > 64) bx = 64;
@@ -236,6 +240,7 @@ extern "C" int babe_gn_bwd_partial(const float* x, const float* da, const float*
                                    int G, long hw, int S, void* stream) {
     BABE_CHECK_ARG(x && da && scale && part, "gn_bwd_partial: null pointer");
     BABE_CHECK_ARG(hw % 4 == 0 && C % G == 0, "gn_bwd_partial: hw=%ld C=%d G=%d unsupported", hw, C, G);
+    BabeProfScope prof(BABE_SLOT_GN_BWD_PARTIAL, 8.0 * B * C * (double)hw, 0, 0, stream);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(S, B * G), dim3(256), 0, (hipStream_t)stream, x, da, scale,
                        part, C, G, hw, S);
     BABE_LAUNCH_CHECK();
@@ -247,6 +252,7 @@ extern "C" int babe_gn_bwd_apply(const float* x, const float* da, const float* g
                                  long hw, int S, float eps, void* stream) {
     BABE_CHECK_ARG(x && da && scale && stats && part && gx, "gn_bwd_apply: null pointer");
     BABE_CHECK_ARG(hw % 4 == 0 && C % G == 0, "gn_bwd_apply: hw=%ld C=%d G=%d unsupported", hw, C, G);
+    BabeProfScope prof(BABE_SLOT_GN_BWD_APPLY, (gy ? 16.0 : 12.0) * B * C * (double)hw, 0, 0, stream);
     int bx = cdiv(hw / 4, 256 * 4);
     if (bx < 1) bx = 1;
     if (bx > 64) bx = 64;

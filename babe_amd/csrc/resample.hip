@@ -7,6 +7,7 @@
 // HBM-bound: one thread per output sample, rows are contiguous in T.
 #include "common.h"
 #include "../../include/babe_hip.h"
+#include "prof.h"
 
 namespace {
 __constant__ float kH[8] = {-0.01171875f, -0.03515625f, 0.11328125f, 0.43359375f,
@@ -140,6 +141,7 @@ extern "C" int babe_resample(const float* in, long in_bs, long in_cs, float* out
     // 4 outputs per thread (16-byte stores) when the output rows keep 16-byte alignment
     const bool v4 = (Tout % 4 == 0) && (((uintptr_t)out & 15) == 0) && (out_bs % 4 == 0) && (out_cs % 4 == 0);
     const long total = (long)F * Tout;
+    BabeProfScope prof(BABE_SLOT_RESAMPLE, 4.0 * B * C * (double)F * ((mode == 0 || mode == 1 ? T : (mode == 2 ? T / 2 : 2 * T)) + (beta != 0.f ? 2 : 1) * (double)Tout), 0, 0, stream);
     if (v4)
         hipLaunchKernelGGL(resample_kernel<4>, dim3(cdiv(total / 4, 256), B * C), dim3(256), 0, (hipStream_t)stream, in,
                            in_bs, in_cs, out, out_bs, out_cs, C, F, T, mode, alpha, beta);

@@ -2,6 +2,7 @@
 // diff_params/edm.py:144-159).  Trivially HBM-bound: float4 streaming, double partial sums.
 #include "common.h"
 #include "../../include/babe_hip.h"
+#include "prof.h"
 
 namespace {
 
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256) void mask_blend_kernel(float* __restrict__ out
 extern "C" int babe_mask_blend(float* out, const float* mask, long mask_bs, const float* a, const float* b_, int B,
                                long n, void* stream) {
     BABE_CHECK_ARG(out && mask && (a || b_) && B > 0 && n > 0, "mask_blend: bad arguments");
+    BabeProfScope prof(BABE_SLOT_SAMPLER, 4.0 * B * (double)n * (2 + (a ? 1 : 0) + (b_ ? 1 : 0)), 0, 0, stream);
     int bx = cdiv(n, 1024);
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(mask_blend_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, out, mask, mask_bs, a, b_, n);
@@ -118,6 +120,7 @@ extern "C" int babe_mask_blend(float* out, const float* mask, long mask_bs, cons
 extern "C" int babe_fir_same(const float* x, long x_bs, const float* taps, int ntaps, float* out, long out_bs, int B,
                              int L, int adjoint, void* stream) {
     BABE_CHECK_ARG(x && taps && out && B > 0 && L > 0 && ntaps > 0 && ntaps <= 4096, "fir_same: bad arguments");
+    BabeProfScope prof(BABE_SLOT_SAMPLER, 8.0 * B * (double)L, 2.0 * B * (double)L * ntaps, 0, stream);
     const size_t lds = (size_t)(ntaps + 1024 + ntaps - 1) * sizeof(float);
     hipLaunchKernelGGL(fir_same_kernel, dim3(cdiv(L, 1024), B), dim3(256), lds, (hipStream_t)stream, x, x_bs, taps,
                        ntaps, out, out_bs, L, adjoint);
@@ -128,6 +131,7 @@ extern "C" int babe_fir_same(const float* x, long x_bs, const float* taps, int n
 extern "C" int babe_lincomb3(float* out, float a, const float* x, float b, const float* y, float c, const float* z,
                              long n, void* stream) {
     BABE_CHECK_ARG(out && x && n > 0, "lincomb3: bad arguments");
+    BabeProfScope prof(BABE_SLOT_SAMPLER, 4.0 * (double)n * (2 + (y ? 1 : 0) + (z ? 1 : 0)), 0, 0, stream);
     int bx = cdiv(n, 1024);
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(lincomb3_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, out, a, x, b, y, c, z, n);
@@ -137,6 +141,7 @@ extern "C" int babe_lincomb3(float* out, float a, const float* x, float b, const
 
 extern "C" int babe_sumsq_partial(const float* g, long g_bs, double* part, int nblk, int B, long n, void* stream) {
     BABE_CHECK_ARG(g && part && nblk > 0 && B > 0 && n > 0, "sumsq_partial: bad arguments");
+    BabeProfScope prof(BABE_SLOT_SAMPLER, 4.0 * B * (double)n, 0, 0, stream);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, g, g_bs, part, nblk, n);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
@@ -146,6 +151,7 @@ extern "C" int babe_score_direction(const float* xden, const float* xhat, const 
                                     float* d, float t, float xi, float audio_len, int shared_norm, int mode, int B,
                                     long n, void* stream) {
     BABE_CHECK_ARG(xden && xhat && g && part && d && B > 0 && n > 0 && t > 0, "score_direction: bad arguments");
+    BabeProfScope prof(BABE_SLOT_SAMPLER, 16.0 * B * (double)n, 0, 0, stream);
     int bx = cdiv(n, 1024);
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(score_direction_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, xden, xhat, g, part,

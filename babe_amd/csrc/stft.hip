@@ -6,6 +6,7 @@
 #include "common.h"
 #include "fft_lds.h"
 #include "../../include/babe_hip.h"
+#include "prof.h"
 
 namespace {
 
@@ -357,6 +358,7 @@ extern "C" int babe_stft_fwd(const float* x, long x_bs, int L, const float* pre,
     BABE_CHECK_ARG(x && spec && tw4096 && B > 0 && L > 0, "stft_fwd: bad arguments");
     BABE_CHECK_ARG(lg >= 8 && lg <= 12, "stft_fwd: nfft=%d unsupported (256..4096, power of two)", nfft);
     BABE_CHECK_ARG(frames == 1 + L / (nfft / 2), "stft_fwd: frames=%d inconsistent with L=%d", frames, L);
+    BabeProfScope prof(BABE_SLOT_STFT_FWD, (double)B * (4.0 * L * (pre ? 2 : 1) + 8.0 * frames * (nfft / 2 + 1)), 0, 0, stream);
     hipLaunchKernelGGL(stft_fwd_kernel, dim3(frames, B), dim3(256), 0, (hipStream_t)stream, x, x_bs, L, pre, spec, lg,
                        frames, reinterpret_cast<const float2*>(tw4096));
     BABE_LAUNCH_CHECK();
@@ -368,6 +370,7 @@ extern "C" int babe_spec_filter_istft(const float* spec, const float* H, long H_
     const int lg = ilog2_exact(nfft);
     BABE_CHECK_ARG(spec && H && frames_out && tw4096 && B > 0 && frames > 0, "spec_filter_istft: bad arguments");
     BABE_CHECK_ARG(lg >= 8 && lg <= 12, "spec_filter_istft: nfft=%d unsupported", nfft);
+    BabeProfScope prof(BABE_SLOT_ISTFT, (double)B * frames * (8.0 * (nfft / 2 + 1) + 4.0 * nfft), 0, 0, stream);
     hipLaunchKernelGGL(spec_filter_istft_kernel, dim3(frames, B), dim3(256), 0, (hipStream_t)stream, spec, H, H_bs,
                        frames_out, lg, frames, reinterpret_cast<const float2*>(tw4096));
     BABE_LAUNCH_CHECK();
@@ -378,6 +381,7 @@ extern "C" int babe_ola(const float* frames_in, const float* post, const float* 
                         double* part, int nblk, int B, int L, int nfft, int frames, void* stream) {
     BABE_CHECK_ARG(frames_in && out && B > 0 && L > 0 && nblk > 0, "ola: bad arguments");
     BABE_CHECK_ARG(!y || part, "ola: residual mode needs a partial-sum buffer");
+    BabeProfScope prof(BABE_SLOT_ISTFT, (double)B * (4.0 * frames * nfft + 4.0 * L * (y ? 2 : 1)), 0, 0, stream);
     hipLaunchKernelGGL(ola_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, frames_in, post, y, y_bs, out,
                        out_bs, y ? part : nullptr, nblk, L, nfft, frames);
     BABE_LAUNCH_CHECK();
@@ -387,6 +391,7 @@ extern "C" int babe_ola(const float* frames_in, const float* post, const float* 
 extern "C" int babe_residual_seed(const float* r, long r_bs, const double* part, int nblk, const float* post,
                                   float* out, long out_bs, int B, int L, void* stream) {
     BABE_CHECK_ARG(r && part && out && B > 0 && L > 0, "residual_seed: bad arguments");
+    BabeProfScope prof(BABE_SLOT_ISTFT, 8.0 * B * (double)L, 0, 0, stream);
     int bx = cdiv(L, 1024);
     hipLaunchKernelGGL(residual_seed_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, r, r_bs, part, nblk, post,
                        out, out_bs, L);
@@ -397,6 +402,7 @@ extern "C" int babe_residual_seed(const float* r, long r_bs, const double* part,
 extern "C" int babe_stft_mag_stats(const float* specX, const float* specY, double* stats, int B, int nbins, int frames,
                                    int shared, void* stream) {
     BABE_CHECK_ARG(specX && specY && stats && B > 0 && nbins > 1 && frames > 0, "stft_mag_stats: bad arguments");
+    BabeProfScope prof(BABE_SLOT_MAG_STATS, 16.0 * B * (double)nbins * frames, 0, 0, stream);
     hipLaunchKernelGGL(mag_stats_kernel, dim3(cdiv(nbins, 256), shared ? 1 : B), dim3(256), 0, (hipStream_t)stream,
                        specX, specY, stats, B, nbins, frames, shared);
     BABE_LAUNCH_CHECK();
@@ -406,6 +412,7 @@ extern "C" int babe_stft_mag_stats(const float* specX, const float* specY, doubl
 extern "C" int babe_design_filter(const float* params, float* H, int P, int K, int nbins, float fs, int nfft,
                                   void* stream) {
     BABE_CHECK_ARG(params && H && P > 0 && K > 0 && K <= KMAX && nbins > 1, "design_filter: bad arguments (K<=8)");
+    BabeProfScope prof(BABE_SLOT_FILTER_FIT, 4.0 * P * (double)nbins, 0, 0, stream);
     const float df = fs / (float)nfft;
     hipLaunchKernelGGL(design_filter_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, params, H, K, nbins, df);
     BABE_LAUNCH_CHECK();
@@ -415,6 +422,7 @@ extern "C" int babe_design_filter(const float* params, float* H, int P, int K, i
 extern "C" int babe_filter_fit(const double* stats, float* params, int* n_iter, int P, int K, int nbins, float fs,
                                int nfft, const babe_fit_cfg* cfg, void* stream) {
     BABE_CHECK_ARG(stats && params && cfg && P > 0 && K > 0 && K <= KMAX && nbins > 1, "filter_fit: bad arguments");
+    BabeProfScope prof(BABE_SLOT_FILTER_FIT, 24.0 * P * (double)nbins, 0, 0, stream);
     const float df = fs / (float)nfft;
     hipLaunchKernelGGL(filter_fit_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, stats, params, n_iter, K, nbins,
                        df, *cfg);

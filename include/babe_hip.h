@@ -65,12 +65,18 @@ int babe_conv2d_wino4_supported(const babe_conv_args* a);
 int babe_conv_pack_weights_wino4(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
                                  void* stream);
 long babe_conv_packed_size_wino4(int Cout, int Cin, int KH, int transpose_flip);
-/* Measurement hook (bench.py): when enabled every babe_conv2d launch is bracketed by HIP events on its
- * stream; read returns the summed kernel time, the summed ALGORITHMIC flops (2*B*Cout*Cin*KH*KW*F*T with the
- * unpadded channel counts) and the launch count, then resets. */
-int babe_conv_prof_enable(int on);
-int babe_conv_prof_pause(int paused);   /* exclude launches (the DFT stages of the CQT) from the tally */
-int babe_conv_prof_read(double* ms_total, double* flops_total, long* launches);
+/* Measurement hook (bench.py; csrc/prof.h lists the slots): when enabled EVERY entry point of this library brackets
+ * its launch with HIP events on the launch stream and tallies, per slot, the kernel time, the ALGORITHMIC bytes and flops
+ * (conv: 2*B*Cout*Cin*KH*KW*F*T with the unpadded channel counts) and the flops the matrix pipe executes (Winograd
+ * F(2,3): 2/3, F(4,3): 1/2 of the algorithmic count).  babe_prof_read() waits for the events, fills arrays of
+ * babe_prof_nslots() entries and resets.  babe_prof_dispatch_counts() is always on: launches per slot, i.e. which
+ * kernel a conv call really dispatched to.  Diagnostics only; single host thread. */
+int babe_prof_nslots(void);
+const char* babe_prof_slot_name(int slot);
+int babe_prof_enable(int on);
+int babe_prof_conv_slot(int slot);      /* >= 0: tally conv launches in that slot (the CQT's dense DFT stages); -1: off */
+int babe_prof_read(double* ms, double* bytes, double* flops, double* exec_flops, long* launches);
+int babe_prof_dispatch_counts(long* counts, int reset);
 
 /* ---- BiasFreeGroupNorm + FiLM + GELU: cqtdiff+.py:147-163, :472-482 ------------------------ */
 /* partial sums (double) of x and x^2 per (b,group,split): part[(b*G+g)*S+s] = {sum, sumsq} */
@@ -126,6 +132,8 @@ typedef struct {
     const float* tw4096; /* [2048] float2 exp(-2 pi i q/4096)                 */
     int nocts; int binsoct;
     float* coef[8];      /* per octave planar [B][2][binsoct][T_oct]          */
+    long sum_T, sum_M;   /* sum over bands of T_k and M_k (for the measurement hook's algorithmic bytes) */
+    double sum_TlogT;    /* sum over bands of T_k*log2(T_k) (algorithmic FFT flops = 5*that)            */
 } babe_cqt_bands;
 /* analysis-type: coef_k = IFFT_T(fold(spec[(c_k+m) mod L] * win[woff_k+m']))  (win carries 1/T and any scale).
  * Used for CQT.fwd (win = g/T) and for the adjoint of CQT.bwd (win = (2/L) T^2 gd). */

@@ -449,7 +449,33 @@ def g11():
     save("denoiser.npz", **out)
 
 
+# ---------------------------------------------------------------- G12: full-width UNet (the benchmarked geometry)
+from tests.golden_weights import full_width_sd  # noqa: E402
+
+
+def g12(lengths=(46046, 368368)):
+    """networks/cqtdiff+.py:730-845 forward + autograd input-gradient of the IMPORTED reference at full width
+    (Ns=[64,96,96,128,128,256,256], 44.1 kHz) - L=46046 (1/8 segment) and L=368368 (the benchmark's segment)."""
+    import time
+    for L in lengths:
+        args = ref_shim.load_args(exp="maestro44k_8s")
+        args.exp.audio_len = L
+        with quiet():
+            net = net_mod.Unet_CQT_oct_with_attention(args, "cpu")
+        net.load_state_dict(full_width_sd(0))
+        g = torch.Generator().manual_seed(3000 + L)
+        x = (0.1 * torch.randn(1, L, generator=g)).requires_grad_(True)
+        cn = torch.tensor([[-0.4]])
+        t0 = time.time()
+        y = net(x, cn)
+        wv = torch.randn(y.shape, generator=g)
+        gx, = torch.autograd.grad((y * wv).sum(), x)
+        print(f"L={L}: reference fwd+grad {time.time() - t0:.0f} s")
+        save(f"unet_full_{L}.npz", seed=3000 + L, wseed=0, cnoise=cn, y=y.detach(), gx=gx)
+        del net, y, gx
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

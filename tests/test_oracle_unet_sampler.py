@@ -134,3 +134,21 @@ def test_predict_bwe_AR_T3():
     smp = OracleBlindSampler(net, cqt, p, fs=22050, audio_len=L, T=3, start_sigma=float(s["start_sigma"]))
     x = predict_bwe_AR(smp, s["ylpf"], y_masked, torch.tensor([[2000.0], [-40.0]]), mask, noises)
     assert rel(x, s["x"]) < 1e-3
+
+
+def test_unet_full_width_vs_reference_golden():
+    """G7 at FULL width - Ns=[64,96,96,128,128,256,256], 44.1 kHz, L=46046 (1/8 segment): oracle forward and
+    autograd input-gradient vs the imported reference (networks/cqtdiff+.py:730-845); pins the checker bench.py's
+    cpu_baseline and the full-width GPU parity tests rely on."""
+    from tests.golden_weights import FULL_DILS, full_width_sd
+    g = load("unet_full_46046.npz")
+    L = 46046
+    sd = full_width_sd(int(g["wseed"]))
+    cqt = CQT_nsgt(7, 64, "oct", ("kaiser", 1), 44100, L)
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    x = (0.1 * torch.randn(1, L, generator=gen)).requires_grad_(True)
+    y = UN.unet_forward(sd, dict(num_octs=7, bins_per_oct=64, num_dils=FULL_DILS), cqt, x, g["cnoise"])
+    assert rel(y, g["y"]) < 1e-5
+    wv = torch.randn(y.shape, generator=gen)
+    gx, = torch.autograd.grad((y * wv).sum(), x)
+    assert rel(gx, g["gx"]) < 1e-4
