@@ -59,11 +59,10 @@ extern "C" void babe_prof_end(void* stream) {
 }
 extern "C" int babe_prof_nslots(void) { return BABE_NSLOTS; }
 extern "C" const char* babe_prof_slot_name(int slot) { return (slot >= 0 && slot < BABE_NSLOTS) ? kSlotNames[slot] : ""; }
+/* on: start tallying (a fresh tally unless one is pending); off: stop, what was recorded stays until babe_prof_read() */
 extern "C" int babe_prof_enable(int on) {
     g_prof.on = on != 0;
-    g_prof.used = 0;
     g_prof.open = false;
-    for (int i = 0; i < BABE_NSLOTS; ++i) g_prof.bytes[i] = g_prof.flops[i] = g_prof.exec[i] = 0;
     return BABE_OK;
 }
 extern "C" int babe_prof_conv_slot(int slot) {

@@ -118,6 +118,9 @@ class BlindSampler:
         B, L = x.shape
         x_den = self.get_denoised_estimate(x, t)
         cskip, cout, cin = self._c
+        if y is None:
+            # unconditional (get_score :160-170): d = -t*(x_den - x)/t^2
+            return lincomb(torch.empty_like(x), 1.0 / float(t), x, -1.0 / float(t), x_den), x_den, filter_params
         if self.ar_mask is not None:
             # mask-mixed degradation of predict_bwe_AR (:280-288): mask*x + (1-mask)*A(x), A = fc_A filter or FIR
             m = self.ar_mask
@@ -174,45 +177,67 @@ class BlindSampler:
         return d, x_den, filter_params
 
     # ------------------------------------------------------------------ sampling loops
-    def _sample(self, y, filter_params, blind, rid, snoise=1.0):
-        dp = self.diff_params
-        device = y.device
-        y = y.contiguous().float()
-        B, L = y.shape
-        st = self.stft_ops(L, device)
-        specY = st.stft(y)
-        T = self.nb_steps
-        if rid:
-            data_denoised = torch.zeros((T, B, L))
-            data_filters = torch.zeros((T, *filter_params.shape[-2:])) if filter_params.shape[0] == 1 else \
-                torch.zeros((T, *filter_params.shape))
-        if self.start_sigma is None:
-            t = dp.create_schedule(T)
-            x = self._randn((B, L), device) * float(t[0])
+    def step(self, x, t_i, gamma_i, t_next, eps, y, specY, filter_params, blind, snoise=1.0):
+        """ONE stochastic Heun step of the reverse diffusion (:687-761 / predict :439-480): noise injection
+        (move_timestep :509-516), score evaluation, 2nd-order correction unless t_next == 0 or order == 1.
+        Returns (x_next, filter_params, rec) with rec = dict(x_hat, t_hat, x_den, d) of the first evaluation.
+        Exposed so that a step can be teacher-forced from recorded reference state (tests/test_gpu_sampler.py)."""
+        t_hat = t_i + gamma_i * t_i
+        x_hat = lincomb(torch.empty_like(x), 1.0, x, float((t_hat ** 2 - t_i ** 2) ** (1 / 2)) * float(snoise), eps)
+        d, x_den, filter_params = self.evaluate(x_hat, float(t_hat), y, specY, filter_params, blind)
+        rec = dict(x_hat=x_hat, t_hat=float(t_hat), x_den=x_den, d=d, filter_params=filter_params)
+        h = float(t_next - t_hat)
+        if float(t_next) != 0 and self.order == 2:
+            x_prime = lincomb(torch.empty_like(x), 1.0, x_hat, h, d)
+            d2, _, filter_params = self.evaluate(x_prime, float(t_next), y, specY, filter_params, blind)
+            x = lincomb(torch.empty_like(x), 1.0, x_hat, 0.5 * h, d, 0.5 * h, d2)
         else:
-            t = dp.create_schedule_from_initial_t(self.start_sigma, T)
-            x = lincomb(torch.empty_like(y), 1.0, y, float(t[0]), self._randn((B, L), device).contiguous())
-        gamma = dp.get_gamma(t)
-        for i in range(T):
-            # move_timestep (:509-516), Snoise = 1 as in predict_blind_bwe (:687)
-            t_hat = t[i] + gamma[i] * t[i]
-            eps = self._randn((B, L), device).contiguous()
-            x_hat = lincomb(torch.empty_like(x), 1.0, x, float((t_hat ** 2 - t[i] ** 2) ** (1 / 2)) * float(snoise), eps)
-            d, x_den, filter_params = self.evaluate(x_hat, float(t_hat), y, specY, filter_params, blind)
+            x = lincomb(torch.empty_like(x), 1.0, x_hat, h, d)
+        return x, filter_params, rec
+
+    def _sample(self, y, filter_params, blind, rid, snoise=1.0, shape=None, device=None):
+        """y None: unconditional sampling of `shape` on `device` (predict_unconditional :366-374)."""
+        dp = self.diff_params
+        if y is not None:
+            device = y.device
+            y = y.contiguous().float()
+            shape = y.shape
+        B, L = shape
+        with torch.cuda.device(device):
+            st = self.stft_ops(L, device)
+            specY = st.stft(y) if (y is not None and self.fir_taps is None) else None
+            T = self.nb_steps
             if rid:
-                data_denoised[i] = x_den.cpu()
-                data_filters[i] = (filter_params[0] if filter_params.shape[0] == 1 else filter_params).cpu()
-            h = float(t[i + 1] - t_hat)
-            if float(t[i + 1]) != 0 and self.order == 2:
-                x_prime = lincomb(torch.empty_like(x), 1.0, x_hat, h, d)
-                d2, _, filter_params = self.evaluate(x_prime, float(t[i + 1]), y, specY, filter_params, blind)
-                x = lincomb(torch.empty_like(x), 1.0, x_hat, 0.5 * h, d, 0.5 * h, d2)
+                data_denoised = torch.zeros((T, B, L))
+                if blind:
+                    data_filters = torch.zeros((T, *filter_params.shape[-2:])) if filter_params.shape[0] == 1 else \
+                        torch.zeros((T, *filter_params.shape))
+                else:
+                    data_score = torch.zeros((T, B, L))
+            if self.start_sigma is None or y is None:
+                t = dp.create_schedule(T)
+                x = lincomb(torch.empty(B, L, device=device), float(t[0]), self._randn((B, L), device).contiguous())
             else:
-                x = lincomb(torch.empty_like(x), 1.0, x_hat, h, d)
-        fp_out = filter_params[0] if (filter_params.shape[0] == 1) else filter_params
-        if rid:
-            return x, fp_out, data_denoised, t, data_filters
-        return x, fp_out
+                t = dp.create_schedule_from_initial_t(self.start_sigma, T)
+                x = lincomb(torch.empty_like(y), 1.0, y, float(t[0]), self._randn((B, L), device).contiguous())
+            gamma = dp.get_gamma(t)
+            for i in range(T):
+                eps = self._randn((B, L), device).contiguous()
+                x, filter_params, rec = self.step(x, t[i], gamma[i], t[i + 1], eps, y, specY, filter_params, blind, snoise)
+                if rid and blind:
+                    # predict_blind_bwe records the denoised estimate BEFORE guidance (x_den_2, :720) and the filter
+                    data_denoised[i] = rec["x_den"].cpu()
+                    fp1 = rec["filter_params"]
+                    data_filters[i] = (fp1[0] if fp1.shape[0] == 1 else fp1).cpu()
+                elif rid:
+                    # predict records the guided Tweedie estimate score*t^2 + x_hat = x_hat - t*d and the score (:452-454)
+                    th = rec["t_hat"]
+                    data_denoised[i] = lincomb(torch.empty_like(x), 1.0, rec["x_hat"], -th, rec["d"]).cpu()
+                    data_score[i] = lincomb(torch.empty_like(x), -1.0 / th, rec["d"]).cpu()
+        if blind:
+            fp_out = filter_params[0] if (filter_params.shape[0] == 1) else filter_params
+            return (x, fp_out, data_denoised, t, data_filters) if rid else (x, fp_out)
+        return (x, data_denoised, data_score, t) if rid else (x,)
 
     def _init_params(self, B, device):
         ic = self.args.tester.blind_bwe.initial_conditions
@@ -223,21 +248,40 @@ class BlindSampler:
         return p.unsqueeze(0).repeat(P, 1, 1).contiguous().to(device)
 
     def predict_blind_bwe(self, y, rid=False, compute_sweep=False):
-        """y [B,L] observations on the GPU -> (x, filter_params[, data_denoised, t, data_filters])."""
+        """y [B,L] observations on the GPU -> (x, filter_params[, data_denoised, t, data_filters])  (:619-769)."""
         if compute_sweep:
             raise NotImplementedError("compute_sweep (logging only)")
         return self._sample(y, self._init_params(y.shape[0], y.device), blind=True, rid=rid)
 
     def predict_bwe(self, ylpf, filt, filt_type, rid=False, test_filter_fit=False, compute_sweep=False):
-        """Known-degradation variant (:306-364). Implemented: filt_type='fc_A' (filt = [2,K] tensor)."""
-        if filt_type != "fc_A":
-            raise NotImplementedError(f"filt_type={filt_type!r}: only 'fc_A' runs on the HIP path")
+        """Known-degradation variant (:306-364 -> predict_conditional :387-404 -> predict :406-498).
+        filt_type 'fc_A' (filt = [2,K] breakpoints) or 'firwin' / 'firwin_hpf' (filt = FIR taps applied with
+        conv1d(padding="same"), :211-218).  rid=True returns (x, data_denoised, data_score, t) like predict."""
         if test_filter_fit or compute_sweep:
             raise NotImplementedError("test_filter_fit / compute_sweep (logging only)")
-        p = torch.as_tensor(filt, dtype=torch.float32)
-        if p.dim() == 1:
-            p = p.unsqueeze(1)
-        res = self._sample(ylpf, p.unsqueeze(0).contiguous().to(ylpf.device), blind=False, rid=rid)
+        dev = ylpf.device
+        if filt_type == "fc_A":
+            p = torch.as_tensor(filt, dtype=torch.float32)
+            if p.dim() == 1:
+                p = p.unsqueeze(1)
+            params = p.unsqueeze(0).contiguous().to(dev)
+            self.fir_taps = None
+        elif filt_type in ("firwin", "firwin_hpf"):
+            self.fir_taps = torch.as_tensor(filt, dtype=torch.float32).reshape(-1).contiguous().to(dev)
+            params = torch.zeros(1, 2, 1, device=dev)
+        else:
+            raise NotImplementedError(f"filt_type={filt_type!r}: 'fc_A' and 'firwin' run on the HIP path (the IIR / "
+                                      f"resample degradations are torchaudio paths no target config uses)")
+        try:
+            res = self._sample(ylpf, params, blind=False, rid=rid, snoise=self.diff_params.Snoise)
+        finally:
+            self.fir_taps = None
+        return res if rid else res[0]
+
+    def predict_unconditional(self, shape, device, rid=False):
+        """Unguided sampling from the prior (:366-374): score = (D(x) - x)/t^2, no observations."""
+        res = self._sample(None, None, blind=False, rid=rid, snoise=self.diff_params.Snoise, shape=tuple(shape),
+                           device=torch.device(device))
         return res if rid else res[0]
 
     # ------------------------------------------------------------------ autoregressive out-painting ("next" row 2)

@@ -52,11 +52,16 @@ class Sampler(BlindSampler):
         self.fir_taps = torch.as_tensor(filt, dtype=torch.float32).reshape(-1).contiguous().to(ylpf.device)
         return self.predict_conditional(ylpf)
 
-    def predict_conditional(self, y):
+    def predict_unconditional(self, shape, device):
+        """Unguided sampling (edm_sampler.py:231-243 -> predict :166-229 with y = None)."""
+        return self.predict_conditional(None, shape=tuple(shape), device=torch.device(device))
+
+    def predict_conditional(self, y, shape=None, device=None):
         dp = self.diff_params
-        y = y.contiguous().float()
-        B, L = y.shape
-        device = y.device
+        if y is not None:
+            y = y.contiguous().float()
+            shape, device = y.shape, y.device
+        B, L = shape
         self.stft_ops(L, device)
         T = self.nb_steps
         if self.rid:

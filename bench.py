@@ -9,11 +9,12 @@ segmentation and cross-fade as formal_test_bwe, testing/blind_bwe_tester.py:421-
 babe_amd/testing/long_file.py) that run as one batch of 2 with per-clip semantics.  Weak scaling: every rank restores its own clips; one RCCL all_gather of
 the restored audio + filters closes each step.
 
-Usage:  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+Usage:  python bench.py --gpus N --steps K --warmup W
+N>1: either launched by torch.distributed.run (one rank per GPU, RANK/LOCAL_RANK/WORLD_SIZE in the env), or run plainly,
+in which case this process spawns the N ranks itself (as a child torch.distributed.run, before touching the GPU).
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes as C
 import json
 import math
 import os
@@ -56,50 +57,122 @@ def synth_clip(clip_id, n=CLIP, fs=FS):
     return x.float()
 
 
-def cpu_baseline(threads):
-    """Oracle (CPU restatement of the reference) timed on one score evaluation of a 1/8-length segment of the
-    same workload: fs=44100, L=46046, full-width network. Cost per audio-second is identical to the
-    L=368368 segment (work is proportional to the number of CQT frames, i.e. to L).  Bounded to <=16
-    threads: with hundreds of threads the many small autograd ops of the reference path get slower."""
+def physical_cores():
+    """Physical core count of the host (unique (physical id, core id) pairs of /proc/cpuinfo); None if unknown."""
+    try:
+        pairs, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((phys, line.split(":")[1].strip()))
+        return len(pairs) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline():
+    """SURVEY 8d protocol.  The oracle (CPU restatement of the reference, pinned at FULL width against the imported
+    reference by tests/golden/unet_full_46046.npz) runs T=2 of the sampler = 3 score evaluations after one warm-up
+    evaluation, on a 46046-sample segment at 44.1 kHz (1/8 of the 368368-sample segment: the work is proportional to
+    the number of CQT frames, i.e. identical cost per audio-second), full-width network; extrapolated x69/3.  Timed at
+    n = min(16, logical CPUs) threads (the headline `value`; with hundreds of threads the many small ops of the
+    reference path get slower) and at n = 8 (comparable with the survey's numbers), with the per-component split."""
     from oracle import edm as E
     from oracle import unet as UN
     from oracle.nsgt import CQT_nsgt as OracleCQT
     from oracle.sampler import OracleBlindSampler
     from babe_amd.networks.cqtdiff_plus import init_state_dict
-    torch.set_num_threads(threads)
     L = 46046
     Ns, nd = [64, 96, 96, 128, 128, 256, 256], [2, 3, 4, 5, 6, 7, 7]
     sd = init_state_dict(Ns, nd, seed=0, gate_scale=1.0)
     cqt = OracleCQT(7, 64, "oct", ("kaiser", 1), FS, L)
     cfg = dict(num_octs=7, bins_per_oct=64, num_dils=nd)
     net = lambda x, cn: UN.unet_forward(sd, cfg, cqt, x, cn)
-    smp = OracleBlindSampler(net, cqt, E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10), fs=FS, audio_len=L, T=35)
+    smp = OracleBlindSampler(net, cqt, E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10), fs=FS, audio_len=L, T=2)
     g = torch.Generator().manual_seed(0)
     y = 0.1 * torch.randn(1, L, generator=g)
     x = y + 0.2 * torch.randn(1, L, generator=g)
-    params = torch.tensor([list(smp.fc_init), list(smp.A_init)], dtype=torch.float32)
-    t0 = time.time()
-    smp.evaluate(x, torch.tensor(0.2), y, params, blind=True)
-    dt = time.time() - t0
-    evals_per_segment = 69
-    value = (L / FS) / (evals_per_segment * dt)
-    return {"value": value, "unit": "audio-sec/s", "cores": threads, "kind": "port",
-            "sample": f"1 of 69 score evaluations (UNet fwd+input-VJP, filter fit, guidance) of a {L}-sample "
-                      f"segment at 44.1 kHz (1/8 of the 368368-sample segment, same cost per audio-second), "
-                      f"full-width network, {dt:.1f} s on {threads} threads, extrapolated x69"}
+    sched = E.schedule(smp.p, 2, 0.2)
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        params = torch.tensor([list(smp.fc_init), list(smp.A_init)], dtype=torch.float32)
+        smp.evaluate(x, sched[0], y, params, blind=True)                    # warm-up evaluation (untimed)
+        timers = {}
+        t0 = time.perf_counter()
+        for tt in (sched[0], sched[1], sched[1]):                           # the 3 evaluations of a T=2 run
+            _, _, params = smp.evaluate(x, tt, y, params, blind=True, timers=timers)
+        return (time.perf_counter() - t0) / 3, {k: round(v / 3, 4) for k, v in timers.items()}
+
+    logical = os.cpu_count() or 1
+    n_main = min(16, logical)
+    dt, split = run(n_main)
+    out = {"value": (L / FS) / (69 * dt), "unit": "audio-sec/s", "cores": n_main, "kind": "port",
+           "physical_cores": physical_cores(), "logical_cpus": logical,
+           "seconds_per_evaluation": round(dt, 4), "split_seconds_per_evaluation": split,
+           "sample": f"T=2 (3 score evaluations after 1 warm-up evaluation: UNet fwd + input-VJP, filter fit, filter apply) "
+                     f"of a {L}-sample segment at 44.1 kHz (1/8 of the 368368-sample segment, same cost per audio-second), "
+                     f"full-width network, {3 * dt:.1f} s on {n_main} threads, extrapolated x69/3"}
+    if n_main != 8 and logical >= 8:
+        dt8, split8 = run(8)
+        out["value_8_threads"] = (L / FS) / (69 * dt8)
+        out["split_seconds_per_evaluation_8_threads"] = split8
+    return out
+
+
+PMC_TRAFFIC_FILE = "r02_conv_traffic.json"
 
 
 def conv_traffic(precision):
-    """HBM-side bytes per conv launch from the committed PMC passes (rocprofv3 cannot run inside the bench):
-    profiles/r01_conv_traffic.json, FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE averaged over the same launches."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_traffic.json")
+    """HBM-side bytes per conv_wino4 launch from the committed PMC passes (rocprofv3 cannot run inside the bench; the
+    passes are separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this command, profiles/README.md)."""
+    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     if precision != "f32" or not os.path.exists(path):
         return None
     with open(path) as f:
         t = json.load(f)
     return {"bytes_per_launch": round(t["bytes_per_launch"]), "fetch": round(t["fetch_bytes_per_launch"]),
             "write": round(t["write_bytes_per_launch"]), "unit": "bytes per launch",
-            "source": "profiles/r01_conv_traffic.json (PMC passes, not live)"}
+            "source": f"profiles/{PMC_TRAFFIC_FILE} (separate PMC passes of this command, not live)"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks under torch.distributed.run as a CHILD process
+    (this parent never touches the GPU) and relay their output and exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+HBM_SLOTS = ["conv11", "gn_stats", "scale_gelu", "gn_bwd_partial", "gn_bwd_apply", "resample", "axpby", "cqt_band_analysis",
+             "cqt_band_synthesis", "cqt_gather", "stft_fwd", "istft", "mag_stats", "sampler"]
+CONV_SLOTS = ["conv53_wino4", "conv53_wino2", "conv53_direct", "conv11", "conv_bf16"]
+
+
+def slot_table(prof, names, wall_s=None):
+    out = {}
+    for k in names:
+        r = prof.get(k)
+        if not r or not r["launches"]:
+            continue
+        sec = r["ms"] * 1e-3
+        e = {"launches": r["launches"], "avg_us": round(r["ms"] * 1e3 / r["launches"], 2),
+             "GB_per_s": round(r["bytes"] / sec / 1e9, 1), "frac_of_hbm_peak": round(r["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4),
+             "MB_per_launch": round(r["bytes"] / r["launches"] / 1e6, 3)}
+        if r["flops"]:
+            e["TFLOP_per_s"] = round(r["flops"] / sec / 1e12, 2)
+        if wall_s:
+            e["share_of_step"] = round(sec / wall_s, 4)
+        out[k] = e
+    return out
 
 
 def main():
@@ -115,13 +188,18 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="conv arithmetic: f32 = exact fp32 MFMA (the benchmark's dtype); bf16x3 / bf16 = bf16 MFMA with "
                          "fp32 storage+accumulation (reported with their own dtype string, never as f32)")
-    ap.add_argument("--profile-convs", type=int, default=1)
+    ap.add_argument("--profile-steps", type=int, default=2,
+                    help="timed steps whose launches are bracketed by HIP events (0 = no roofline/hbm blocks)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))                  # before anything touches the GPU in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                 f"--nproc-per-node {a.gpus} (or without a launcher, which spawns the ranks itself)")
     import torch.distributed as dist
     ndev = torch.cuda.device_count()
     dev_idx = local_rank % max(ndev, 1)          # (== local_rank on a real N-GPU node; lets 2 ranks share 1 GPU in tests)
@@ -137,7 +215,7 @@ def main():
 
     import __graft_entry__ as ge
     ge.build()
-    from babe_amd._lib import lib
+    from babe_amd import _lib
     from babe_amd.config import default_args
     from babe_amd.diff_params.edm import EDM
     from babe_amd.dist import gather_results
@@ -177,44 +255,47 @@ def main():
         fpc = fp.reshape(C_, -1)
         return gather_results(clips, fpc) if world > 1 else (clips, fpc)
 
-    L_ = lib()
-    L_.babe_conv_prof_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
-    # Warm-up.  The LAST warm-up step also measures the conv launches with every batch item on one stream (kernels
-    # serialised, so a launch duration is that kernel alone); the timed region below runs batch items on two streams and
-    # its per-launch durations include the overlap with the other stream's kernels.
+    do_prof = a.profile_steps > 0 and rank == 0
+    # Warm-up.  The LAST warm-up step also measures every launch with all batch items on ONE stream (kernels serialised,
+    # so a launch duration is that kernel alone - the figure a rocprofv3 kernel trace of this command agrees with, since
+    # tracing serialises the lanes too); the timed region below runs batch items on two streams and its per-launch
+    # durations include the overlap with the other stream's kernels.
     serial = None
     for s in range(a.warmup):
-        last = s == a.warmup - 1 and a.profile_convs and rank == 0
+        last = s == a.warmup - 1 and do_prof
         if last:
             lanes_keep, net.MAX_LANES = net.MAX_LANES, 1
             torch.cuda.synchronize()
-            L_.babe_conv_prof_enable(1)
+            _lib.prof_read()
+            _lib.prof_enable(True)
+            t_ser = time.perf_counter()
         one_step(s)
         if last:
             torch.cuda.synchronize()
-            ms0, fl0, nl0 = C.c_double(0), C.c_double(0), C.c_long(0)
-            L_.babe_conv_prof_read(C.byref(ms0), C.byref(fl0), C.byref(nl0))
-            L_.babe_conv_prof_enable(0)
+            t_ser = time.perf_counter() - t_ser
+            _lib.prof_enable(False)
+            serial = _lib.prof_read()
             net.MAX_LANES = lanes_keep
-            if ms0.value > 0:
-                serial = (fl0.value / (ms0.value * 1e-3) / 1e12, ms0.value * 1e3 / max(nl0.value, 1))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if a.profile_convs:
-        L_.babe_conv_prof_enable(1)
+    _lib.dispatch_counts(reset=True)
+    if do_prof:
+        _lib.prof_read()
+        _lib.prof_enable(True)
+    n_prof = min(a.profile_steps, a.steps) if do_prof else 0
     t0 = time.perf_counter()
-    for s in range(a.warmup, nsteps):
+    for i, s in enumerate(range(a.warmup, nsteps)):
         out = one_step(s)
+        if do_prof and i + 1 == n_prof:
+            _lib.prof_enable(False)                 # host-side switch only: no sync inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ms, fl, nl = C.c_double(0), C.c_double(0), C.c_long(0)
-    if a.profile_convs:
-        L_.babe_conv_prof_read(C.byref(ms), C.byref(fl), C.byref(nl))
-        L_.babe_conv_prof_enable(0)
+    timed = _lib.prof_read() if do_prof else None
+    counts = _lib.dispatch_counts()
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -223,39 +304,60 @@ def main():
 
     if rank == 0:
         value = world * a.steps * C_ * CLIP_SEC / dt
-        roof = None
+        roof = hbm = None
         dtype = {"f32": "f32", "bf16x3": "bf16x3 (bf16 MFMA on hi/lo-split operands, fp32 storage+accumulate)",
                  "bf16": "bf16 (bf16 MFMA, fp32 storage+accumulate)"}[a.precision]
         peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "f32" else 2500.0
-        kname = ("babe_conv2d launches of the UNet: conv_wino4_kernel (Winograd F(4,3)-along-time, fp32 "
-                 "v_mfma_f32_32x32x2_f32; F(2,3) / direct fallbacks) for the (5,3) layers, conv_mfma_kernel for (1,1); fwd + "
-                 "input-VJP; achieved counts the ALGORITHMIC (direct-convolution) flops - the matrix pipe executes half of "
-                 "them on the (5,3) layers"
-                 if a.precision == "f32" else
-                 "conv_bf16_kernel (v_mfma_f32_32x32x16_bf16; %s products per k-block; achieved counts ALGORITHMIC flops)"
-                 % ("3" if a.precision == "bf16x3" else "1"))
-        if a.profile_convs and ms.value > 0:
+        dom = "conv53_wino4" if a.precision == "f32" else "conv_bf16"
+        if timed is not None and timed[dom]["launches"]:
+            wall_prof = dt * n_prof / a.steps            # wall time of the profiled steps (steps are identical work)
+            r = timed[dom]
+            sec = r["ms"] * 1e-3
+            conv_all = {k: timed[k] for k in CONV_SLOTS}
+            sum_conv_ms = sum(v["ms"] for v in conv_all.values())
+            sum_all_ms = sum(v["ms"] for v in timed.values())
             tr = conv_traffic(a.precision)
-            ach = fl.value / (ms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": (tr or {}).get("bytes_per_launch"), "traffic_detail": tr,
-                    "kernel": kname,
-                    "launches": nl.value, "avg_launch_us": round(ms.value * 1e3 / max(nl.value, 1), 2),
-                    "algorithmic_tflop_per_launch_avg": round(fl.value / max(nl.value, 1) / 1e12, 5),
-                    "kernel_time_share_of_step": round(ms.value * 1e-3 / dt, 4)}
-            roof["concurrency"] = ("batch items run on %d streams: launch durations in the timed region include overlap with "
-                                   "the other stream's kernels (sum of durations / wall = kernel_time_share_of_step)"
-                                   % max(1, min(net.MAX_LANES, nseg * C_)))
+            roof = {
+                "bound": "mfma",
+                "kernel": ("conv_wino4_kernel: Winograd F(4,3)-along-time (5,3) conv, fp32 v_mfma_f32_32x32x2_f32, fwd + "
+                           "input-VJP launches of the UNet" if a.precision == "f32" else
+                           "conv_bf16_kernel (v_mfma_f32_32x32x16_bf16; %s products per k-block)"
+                           % ("3" if a.precision == "bf16x3" else "1")),
+                "achieved": round(r["flops"] / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(r["exec_flops"] / sec / 1e12 / peak, 4),
+                "frac_definition": "EXECUTED MFMA flops / duration / peak (F(4,3) executes 1/2 of the algorithmic "
+                                   "direct-convolution flops that `achieved` counts); algorithmic_frac = achieved / peak",
+                "algorithmic_frac": round(r["flops"] / sec / 1e12 / peak, 4),
+                "executed_tflops": round(r["exec_flops"] / sec / 1e12, 2),
+                "traffic": (tr or {}).get("bytes_per_launch"), "traffic_detail": tr,
+                "algorithmic_MB_per_launch": round(r["bytes"] / r["launches"] / 1e6, 2),
+                "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                "algorithmic_gflop_per_launch_avg": round(r["flops"] / r["launches"] / 1e9, 3),
+                "profiled_steps": n_prof,
+                "timing": "HIP events on each launch's own stream over the first %d step(s) of the timed region; batch "
+                          "items run on %d streams, so these durations include overlap with the other stream's kernels: "
+                          "overlap_factor = sum of all kernel durations / wall time of those steps"
+                          % (n_prof, max(1, min(net.MAX_LANES, nseg * C_))),
+                "overlap_factor": round(sum_all_ms * 1e-3 / wall_prof, 4),
+                "conv_time_share_of_kernel_time": round(sum_conv_ms / sum_all_ms, 4),
+                "conv_dispatch_counts_timed_region": {k: counts[k] for k in CONV_SLOTS + ["dft_stage"]},
+                "all_conv_kernels": slot_table(timed, CONV_SLOTS),
+            }
+            if serial is not None and serial[dom]["launches"]:
+                q = serial[dom]
+                qs = q["ms"] * 1e-3
+                roof["serial"] = {
+                    "what": "same launches with all batch items on ONE stream (last warm-up step): the kernel alone on the "
+                            "GPU; this is what a rocprofv3 kernel trace (which serialises the lanes) agrees with",
+                    "achieved": round(q["flops"] / qs / 1e12, 2), "frac": round(q["exec_flops"] / qs / 1e12 / peak, 4),
+                    "algorithmic_frac": round(q["flops"] / qs / 1e12 / peak, 4),
+                    "avg_launch_us": round(q["ms"] * 1e3 / q["launches"], 2), "launches": q["launches"],
+                    "sum_kernel_time_over_wall": round(sum(v["ms"] for v in serial.values()) * 1e-3 / t_ser, 4),
+                    "all_conv_kernels": slot_table(serial, CONV_SLOTS, t_ser)}
+            hbm = {"peak_GB_per_s": HBM_PEAK_GBS, "bytes": "ALGORITHMIC bytes per launch (each operand touched once), DESIGN.md 3",
+                   "timed_region": slot_table(timed, HBM_SLOTS, wall_prof)}
             if serial is not None:
-                roof["serial_achieved"] = round(serial[0], 2)          # same launches, one stream (last warm-up step)
-                roof["serial_frac"] = round(serial[0] / peak, 4)
-                roof["serial_avg_launch_us"] = round(serial[1], 2)
-            if a.precision == "f32":
-                # 96.6 % of the conv flops of this workload are (5,3) layers (3.897 of 4.034 TFLOP per forward), all
-                # of which qualify for the F(4,3) kernel here; it multiplies half as often as the direct convolution
-                ex = (serial[0] if serial is not None else ach) * (0.966 * 0.5 + 0.034)
-                roof["executed_mfma_tflops_estimate"] = round(ex, 2)
-                roof["executed_frac_of_peak_estimate"] = round(ex / peak, 4)
+                hbm["serial"] = slot_table(serial, HBM_SLOTS, t_ser)
         rec = {
             "metric": "audio-sec/s (blind BWE, 10 s @ 44.1 kHz clips, 35 EDM steps 2nd order), whole job",
             "value": round(value, 5), "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -270,9 +372,10 @@ def main():
             "per_gpu_realtime_factor": round(value / world, 5),
             "output_finite": finite,
             "roofline": roof,
+            "hbm": hbm,
         }
         if world == 1 and not a.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
+            rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()

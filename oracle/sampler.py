@@ -41,14 +41,33 @@ class OracleBlindSampler:
         s = self.xi / (torch.linalg.norm(g) / self.audio_len ** 0.5 + 1e-6)
         return s * g / t
 
-    def evaluate(self, x, t, y, params, blind=True):
-        """One score evaluation. Returns score, x_den (detached), new params."""
+    def evaluate(self, x, t, y, params, blind=True, timers=None):
+        """One score evaluation. Returns score, x_den (detached), new params.
+        timers: optional dict accumulating wall seconds of the components (bench.py's cpu_baseline split):
+        'unet_fwd' (denoiser forward incl. CQT + high-pass), 'fit' (fit_params), 'filter' (filter apply + norm),
+        'vjp' (autograd through iSTFT/STFT/high-pass/UNet)."""
+        import time
+        tick = time.perf_counter
         x = x.detach().requires_grad_(True)
+        t0 = tick()
         x_den = self.denoised(x, t)
+        t1 = tick()
         xd2 = x_den.detach().clone()
         if blind:
             params, _ = U.fit_params(xd2, y, params, **self.fit_kw)
-        rg = self.rec_grads(x_den, y, x, t, params)
+        t2 = tick()
+        if timers is None:
+            rg = self.rec_grads(x_den, y, x, t, params)
+        else:
+            H = U.design_filter(params[0], params[1], self.freqs)
+            rec = U.apply_filter(x_den, H, self.nfft)
+            norm = torch.linalg.norm(y - rec, dim=1, ord=2)
+            t3 = tick()
+            g, = torch.autograd.grad(norm.sum(), x)
+            t4 = tick()
+            rg = self.xi / (torch.linalg.norm(g) / self.audio_len ** 0.5 + 1e-6) * g / t
+            for k, v in (("unet_fwd", t1 - t0), ("fit", t2 - t1), ("filter", t3 - t2), ("vjp", t4 - t3)):
+                timers[k] = timers.get(k, 0.0) + v
         score = (xd2 - x.detach()) / t ** 2 - rg
         return score, xd2, params
 

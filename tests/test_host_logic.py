@@ -169,9 +169,9 @@ def test_committed_bench_line_follows_the_contract():
     import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r01_bench_v[0-9]*.json")),
-                   key=lambda p: int("".join(ch for ch in os.path.basename(p).split("_v")[1].split(".")[0].split("_")[0] if ch.isdigit())))
-    headline = [f for f in files if os.path.basename(f).count("_") == 2]          # r01_bench_vN.json (no suffix)
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r0[0-9]_bench_v[0-9]*.json")),
+                   key=lambda p: (os.path.basename(p)[:3], int("".join(ch for ch in os.path.basename(p).split("_v")[1].split(".")[0].split("_")[0] if ch.isdigit()))))
+    headline = [f for f in files if os.path.basename(f).count("_") == 2]          # rNN_bench_vN.json (no suffix)
     d = json.loads(open(headline[-1]).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -181,9 +181,38 @@ def test_committed_bench_line_follows_the_contract():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["bound"] == "mfma" and 0 < r["frac"] <= 1.0
+    if os.path.basename(headline[-1]).startswith("r01"):
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    else:
+        # round 2 on: frac = EXECUTED MFMA flops / peak for the named kernel, algorithmic_frac = achieved / peak; the hbm
+        # block carries the per-kernel HBM fractions of the CQT / STFT / GroupNorm / resample / (1,1)-conv kernels
+        assert abs(r["algorithmic_frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert abs(r["frac"] - r["executed_tflops"] / r["peak"]) < 1e-3
+        assert r["conv_dispatch_counts_timed_region"]["conv53_direct"] == 0
+        for k in ("cqt_band_analysis", "cqt_band_synthesis", "stft_fwd", "gn_stats", "resample", "conv11"):
+            assert k in d["hbm"]["timed_region"], k
+            assert 0 < d["hbm"]["timed_region"][k]["frac_of_hbm_peak"] < 1
     assert r["traffic"] is None or isinstance(r["traffic"], (int, float))
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1
+
+
+def test_bench_gpus_flag_without_launcher_spawns_ranks_or_fails_loudly(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset must start N ranks (never silently run one); with a launcher whose
+    WORLD_SIZE disagrees it must exit non-zero.  No GPU is touched: the spawn is intercepted."""
+    import sys
+    import bench
+    calls = []
+    monkeypatch.setattr(bench, "spawn_ranks", lambda n: calls.append(n) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert calls == [4] and e.value.code == 0
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code not in (0, None) and calls == [4]

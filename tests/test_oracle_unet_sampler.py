@@ -152,3 +152,52 @@ def test_unet_full_width_vs_reference_golden():
     wv = torch.randn(y.shape, generator=gen)
     gx, = torch.autograd.grad((y * wv).sum(), x)
     assert rel(gx, g["gx"]) < 1e-4
+
+
+def _oracle_sampler(sd, cqt, a, T, start_sigma, L=92092, max_iter=100):
+    """a=None: the network unwrapped (T=35 golden); else the noisy-identity wrapper of the T=3 goldens."""
+    p = E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10, Stmin=0, Stmax=50, Snoise=1.0)
+    if a is None:
+        net = lambda x, cn: UN.unet_forward(sd, CFG, cqt, x, cn)
+    else:
+        net = lambda x, cn: a * UN.unet_forward(sd, CFG, cqt, x, cn) + (torch.exp(4 * cn) / 0.063) * x
+    return OracleBlindSampler(net, cqt, p, fs=22050, audio_len=L, T=T, start_sigma=start_sigma, max_iter=max_iter)
+
+
+def test_sampler_T35_vs_reference_golden():
+    """G8 at the benchmark's schedule (T=35 from sigma=0.2 down to 1e-4, 69 score evaluations): oracle vs the imported
+    reference's predict_blind_bwe (testing/blind_bwe_sampler.py:619-769), per-step denoised estimates and filters."""
+    g, sd, cqt = small_net()
+    s = load("sampler_T35.npz")
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(L, generator=gen)                      # the draw that made the observation
+    noises = [torch.randn(1, L, generator=gen) for _ in range(36)]
+    smp = _oracle_sampler(sd, cqt, None, 35, float(s["start_sigma"]))
+    rec = []
+    x, fp = smp.predict_blind_bwe(s["y"], noises, record=rec)
+    assert torch.equal(E.schedule(smp.p, 35, float(s["start_sigma"])), s["t"])
+    for i in range(35):
+        assert rel(rec[i]["x_den"][:, ::16], s["data_denoised_sub16"][i]) < 1e-3, i
+        assert params_close(rec[i]["params"], s["data_filters"][i]), i
+    rms = float((x - s["x"]).pow(2).mean().sqrt())
+    assert rms < 1e-3 and rel(x, s["x"]) < 2e-3, (rms, rel(x, s["x"]))
+    assert params_close(fp, s["filter_params"])
+
+
+def test_sampler_B2_reference_batch_semantics():
+    """B=2 through the reference's own coupling: ONE filter fitted on the flattened batch (blind_bwe_utils.py:295) and a
+    whole-batch guidance norm (blind_bwe_sampler.py:125)."""
+    g, sd, cqt = small_net()
+    s = load("sampler_B2.npz")
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = [torch.randn(L, generator=gen) for _ in range(2)]
+    noises = [torch.randn(2, L, generator=gen) for _ in range(4)]
+    smp = _oracle_sampler(sd, cqt, float(s["res_a"]), 3, float(s["start_sigma"]), max_iter=int(s["max_iter"]))
+    rec = []
+    x, fp = smp.predict_blind_bwe(s["y"], noises, record=rec)
+    for i in range(3):
+        assert rel(rec[i]["x_den"][:, ::16], s["data_denoised_sub16"][i]) < 1e-3, i
+        assert params_close(rec[i]["params"], s["data_filters"][i]), i
+    assert rel(x, s["x"]) < 1e-3 and params_close(fp, s["filter_params"])
