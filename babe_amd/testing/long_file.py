@@ -120,3 +120,47 @@ def restore_file_AR(sampler, y, filt, filt_type="fc_A", overlap_s=0.25, discard_
     pred = sampler.predict_bwe_AR(seg_zp, y_masked, filt, filt_type, mask=mask)
     out[ix:ix + n] = pred[0, :n]
     return out
+
+
+def restore_recording_complete(sampler, degraded, *, n_segments_blindstep=1, ix_start=0, std=0.1, overlap_s=0.25,
+                               typefilter="fc_A", denoiser=None, rng=None):
+    """Whole-recording flow of BlindTester.test_real_blind_bwe_complete (/root/reference/testing/blind_bwe_tester.py:
+    710-867; with the denoiser pre-pass: testing/denoise_and_bwe_tester.py:248-411, config #5):
+
+      1. optional denoiser pre-pass over the whole file (`denoiser.apply_denoiser`, :279-285 - sequential, not joint);
+      2. normalise the file to `complete_recording.std` (:296-297);
+      3. BLIND step (:307-329): estimate the low-pass filter on `n_segments_blindstep` segments - the one at
+         `ix_start` seconds if 1, else that many segments at `rng.randint(0, L - segL)` (numpy's global generator in the
+         reference) - in ONE batch with the reference's batch coupling (one filter fitted on the flattened batch,
+         whole-batch guidance norm), whatever `sampler.batch_semantics` is set to for independent clips;
+      4. NON-BLIND autoregressive pass over the file with that filter (:350-407, `restore_file_AR`);
+      5. undo the normalisation (:409).
+
+    degraded: [L] or [1, L] device tensor at exp.sample_rate (the torchaudio resampling of the reference is outside this
+    build).  Returns (restored [L], estimated_filter [2, K], blind-step prediction [n, segL])."""
+    import numpy as np
+    rng = rng or np.random
+    args = sampler.args
+    segL = args.exp.audio_len
+    d = degraded.reshape(1, -1).float()
+    if denoiser is not None:
+        d = denoiser.apply_denoiser(d)
+    s = d.std(-1)
+    d = std * d / s.unsqueeze(-1)
+    L = d.shape[-1]
+    ix_first = int(args.exp.sample_rate * ix_start)
+    if n_segments_blindstep == 1:
+        y = d[..., ix_first:ix_first + segL]
+    else:
+        y = d[..., ix_first:ix_first + segL].repeat(n_segments_blindstep, 1)
+        for j in range(n_segments_blindstep):
+            ix = int(rng.randint(0, L - segL))
+            y[j] = d[0, ix:ix + segL]
+    keep = sampler.batch_semantics
+    sampler.batch_semantics = "reference"
+    try:
+        pred, estimated_filter = sampler.predict_blind_bwe(y.contiguous())
+    finally:
+        sampler.batch_semantics = keep
+    out = restore_file_AR(sampler, d[0], estimated_filter, typefilter, overlap_s=overlap_s)
+    return out * (s / std), estimated_filter, pred

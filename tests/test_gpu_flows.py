@@ -1,0 +1,123 @@
+"""Whole-recording flows on the HIP path vs the reference's OWN driver method,
+BlindTester.test_real_blind_bwe_complete (/root/reference/testing/denoise_and_bwe_tester.py:248-411; identical to
+testing/blind_bwe_tester.py:710-867 without the denoiser), run in the build container with file I/O stubbed
+(tests/golden/make_golden.py::g15): [denoiser pre-pass ->] std normalisation -> blind filter estimate on 2 random
+segments in one batch with the reference's batch coupling -> non-blind autoregressive pass with that filter.  Needs a MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rms_err(a, b):
+    return float((a.detach().double().cpu() - torch.as_tensor(b).double().cpu()).pow(2).mean().sqrt())
+
+
+class ResidualNet:
+    """Same wrapper as make_golden.ResidualNetRef: a*net(x,c) + (sigma/sigma_data)*x, sigma = exp(4c)."""
+
+    def __init__(self, inner, a, sigma_data):
+        self.inner, self.a, self.sd = inner, a, sigma_data
+        self.CQTransform = inner.CQTransform
+
+    def fwd_nograd(self, x, cn):
+        self.k = float(torch.exp(4 * cn[0, 0])) / self.sd
+        return self.a * self.inner.fwd_nograd(x, cn) + self.k * x
+
+    def vjp(self, g):
+        return self.a * self.inner.vjp(g) + self.k * g
+
+
+def synth_recording(L, fs, seed):
+    """The input file of g15, re-derived from its seed (oracle utilities are the checker's, not the product's)."""
+    from oracle import bwe_utils as U
+    g = torch.Generator().manual_seed(seed)
+    t_ax = torch.arange(L) / fs
+    clean = sum(0.05 / (k + 1) * torch.sin(2 * np.pi * 196.0 * (k + 1) * t_ax) * torch.exp(-(t_ax % 2.0) * (1 + k)) for k in range(12))
+    clean = clean + 0.1 * torch.randn(L, generator=g)
+    f = torch.fft.rfftfreq(4096, d=1 / fs)
+    return U.apply_filter(clean[None], U.design_filter(torch.tensor([2500.0]), torch.tensor([-35.0]), f), 4096)[0]
+
+
+@pytest.mark.parametrize("use_denoiser", [False, True])
+def test_complete_recording_flow_vs_reference_driver(use_denoiser):
+    from babe_amd.config import default_args
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.networks import denoiser as dn
+    from babe_amd.networks.cqtdiff_plus import Unet_CQT_oct_with_attention
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    from babe_amd.testing.denoise import DenoiserPrepass
+    from babe_amd.testing.long_file import restore_recording_complete
+    s = np.load(os.path.join(G, "complete_recording.npz"))
+    u = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(G, "unet_small.npz")).items()}
+    sd = {k[3:]: v for k, v in u.items() if k.startswith("sd.")}
+    fs, segL, L = 22050, 92092, int(s["L"])
+    args = default_args(sample_rate=fs, audio_len=segL, Ns=[8, 8, 8, 8, 16, 16, 16], T=3, start_sigma=float(s["start_sigma"]))
+    args.tester.blind_bwe.optimization.mu = [float(v) for v in s["mu"]]
+    net = Unet_CQT_oct_with_attention(args, "cuda")
+    net.load_state_dict(sd, strict=True)
+    smp = BlindSampler(ResidualNet(net, float(s["res_a"]), 0.063), EDM(args), args, batch_semantics="per_clip")
+    gn = torch.Generator().manual_seed(int(s["noise_seed"]))
+    smp._randn = lambda shape, device: torch.randn(*shape, generator=gn).to(device)      # the reference's draw order
+    pre = None
+    if use_denoiser:
+        cfg = dict(depth=3, num_tfc=1, num_stages=2, use_SAM=True, use_fencoding=True, f_dim=513)
+        dnet = dn.MultiStage_denoise(cfg)
+        dnet.load_state_dict(dn.init_state_dict(cfg, seed=int(s["dn_seed"])))
+        dnet.to("cuda")
+        pre = DenoiserPrepass(dnet, dict(sample_rate_denoiser=fs, segment_size=5, stft_win_size=1024, stft_hop_size=256,
+                                         num_stages=2), "cuda")
+    rec = synth_recording(L, fs, int(s["seed"])).cuda()
+    np.random.seed(int(s["np_seed"]))                         # the reference picks the blind-step segments with np.random
+    out, filt, blind_pred = restore_recording_complete(smp, rec, n_segments_blindstep=2, ix_start=0, std=0.1, overlap_s=0.25,
+                                                        typefilter="fc_A", denoiser=pre)
+    key = "dn" if use_denoiser else "plain"
+    assert smp.batch_semantics == "per_clip"                  # restored after the coupled blind step
+    assert rel(blind_pred[:, ::16], s[f"{key}_blind_pred_sub16"]) < 2e-3
+    fr = torch.from_numpy(s[f"{key}_blind_filter"])
+    assert torch.allclose(filt.cpu()[0], fr[0], rtol=1e-2) and torch.allclose(filt.cpu()[1], fr[1], atol=1.0), (filt, fr)
+    ref = torch.from_numpy(s[f"{key}_final"])[0]
+    e_rms, e_rel = rms_err(out, ref), rel(out, ref)
+    print(f"complete recording ({key}): RMS err {e_rms:.2e} (signal RMS {float(ref.std()):.3f}), rel {e_rel:.2e}")
+    assert out.shape == ref.shape and e_rel < 3e-3
+
+
+@pytest.mark.parametrize("layout", ["trainer_ema", "ema_weights_all", "ema_weights_trainable"])
+def test_reference_format_checkpoint_restores_into_hip_net(layout, tmp_path):
+    """a checkpoint written the way the reference's trainer writes it (training/trainer.py:273-285:
+    {'it','network','optimizer','ema','args'}) or in the two older 'ema_weights' list layouts that
+    BlindTester.load_checkpoint (testing/blind_bwe_tester.py:238-272) accepts is restored through io.load_checkpoint into
+    the HIP network, which must then reproduce the imported reference's forward (tests/golden/unet_small.npz)."""
+    from babe_amd.config import default_args
+    from babe_amd.io import load_checkpoint
+    from babe_amd.networks.cqtdiff_plus import Unet_CQT_oct_with_attention, init_state_dict
+    u = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(G, "unet_small.npz")).items()}
+    ema = {k[3:]: v for k, v in u.items() if k.startswith("sd.")}
+    Ns = [8, 8, 8, 8, 16, 16, 16]
+    args = default_args(sample_rate=22050, audio_len=92092, Ns=Ns)
+    raw = init_state_dict(Ns, args.network.num_dils, seed=123)            # the non-EMA weights: must NOT be what gets loaded
+    buffers = {k for k in raw if k.endswith(".kernel") or k == "embedding.RFF_freq"}
+    model = {k: (raw[k].clone().requires_grad_(k not in buffers) if k not in buffers else ema[k].clone()) for k in ema}
+    if layout == "trainer_ema":
+        state = {"it": 4321, "network": raw, "optimizer": {"state": {}, "param_groups": []}, "ema": ema, "args": {"exp": "x"}}
+    elif layout == "ema_weights_all":
+        state = {"it": 4321, "model": model, "ema_weights": [ema[k] for k in model]}
+    else:
+        state = {"it": 4321, "model": model, "ema_weights": [ema[k] for k in model if k not in buffers]}
+    path = str(tmp_path / "ckpt.pt")
+    torch.save(state, path)
+    net = Unet_CQT_oct_with_attention(args, "cuda")
+    assert load_checkpoint(net, path) == 4321
+    gen = torch.Generator().manual_seed(int(u["unet_seed"]))
+    x = (0.1 * torch.randn(1, 92092, generator=gen)).cuda()
+    y = net(x, u["unet_cnoise"].cuda())
+    assert rel(y, u["unet_y"]) < 2e-5

@@ -154,14 +154,14 @@ def test_unet_full_width_vs_reference_golden():
     assert rel(gx, g["gx"]) < 1e-4
 
 
-def _oracle_sampler(sd, cqt, a, T, start_sigma, L=92092, max_iter=100):
+def _oracle_sampler(sd, cqt, a, T, start_sigma, L=92092, mu=(1000.0, 10.0)):
     """a=None: the network unwrapped (T=35 golden); else the noisy-identity wrapper of the T=3 goldens."""
     p = E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10, Stmin=0, Stmax=50, Snoise=1.0)
     if a is None:
         net = lambda x, cn: UN.unet_forward(sd, CFG, cqt, x, cn)
     else:
         net = lambda x, cn: a * UN.unet_forward(sd, CFG, cqt, x, cn) + (torch.exp(4 * cn) / 0.063) * x
-    return OracleBlindSampler(net, cqt, p, fs=22050, audio_len=L, T=T, start_sigma=start_sigma, max_iter=max_iter)
+    return OracleBlindSampler(net, cqt, p, fs=22050, audio_len=L, T=T, start_sigma=start_sigma, mu=mu)
 
 
 def test_sampler_T35_vs_reference_golden():
@@ -194,7 +194,7 @@ def test_sampler_B2_reference_batch_semantics():
     gen = torch.Generator().manual_seed(int(s["seed"]))
     _ = [torch.randn(L, generator=gen) for _ in range(2)]
     noises = [torch.randn(2, L, generator=gen) for _ in range(4)]
-    smp = _oracle_sampler(sd, cqt, float(s["res_a"]), 3, float(s["start_sigma"]), max_iter=int(s["max_iter"]))
+    smp = _oracle_sampler(sd, cqt, float(s["res_a"]), 3, float(s["start_sigma"]), mu=tuple(float(v) for v in s["mu"]))
     rec = []
     x, fp = smp.predict_blind_bwe(s["y"], noises, record=rec)
     for i in range(3):
