@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libbabe_hip.so")
-SOURCES = ["misc.hip", "conv.hip", "conv_bf16.hip", "conv_wino.hip", "conv_wino4.hip", "norm.hip", "resample.hip", "cqt.hip", "stft.hip", "sampler.hip", "denoiser.hip"]
+SOURCES = ["misc.hip", "conv.hip", "conv_bf16.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4p.hip", "norm.hip", "resample.hip", "cqt.hip", "stft.hip", "sampler.hip", "denoiser.hip"]
 
 
 def needs_build():
@@ -66,7 +66,8 @@ def _build_locked(force, verbose):
     if failed:
         raise RuntimeError("hipcc failed")
     tmp = OUT + f".tmp{os.getpid()}"
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+    # -z defs: an undefined symbol (e.g. a kernel stub the host pass silently dropped) fails the link, not the first call
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

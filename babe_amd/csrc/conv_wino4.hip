@@ -354,6 +354,9 @@ extern "C" int babe_conv_pack_weights_wino4(const float* w, float* dst, int Cout
     return BABE_OK;
 }
 
+int babe_conv2d_wino4p_supported(const babe_conv_args& a);                              // conv_wino4p.hip
+int babe_conv2d_wino4p_launch(const babe_conv_args& a, const float* w_wino4, hipStream_t s);
+
 /* returns 1 if the F(4,3) kernel can run this problem (the caller then passes the wino4-packed weights) */
 extern "C" int babe_conv2d_wino4_supported(const babe_conv_args* ap) {
     if (!ap) return 0;
@@ -379,7 +382,8 @@ extern "C" int babe_conv2d_wino4(const babe_conv_args* ap, const float* w_wino4,
     hipStream_t s = (hipStream_t)stream;
     const double flops = babe_conv_flops(a);     // F(4,3): 6 multiplies per 4 outputs instead of 12
     BabeProfScope prof(BABE_SLOT_CONV53_WINO4, babe_conv_bytes(a), flops, flops * 0.5, stream);
-    if (n32 == 2) launch4<2, 1, 2>(a, g, w_wino4, s);            //  64 co x 256 positions, 4 waves
+    if (babe_conv2d_wino4p_supported(a)) babe_conv2d_wino4p_launch(a, w_wino4, s);   // pipelined 128 co x 256 pos
+    else if (n32 == 2) launch4<2, 1, 2>(a, g, w_wino4, s);       //  64 co x 256 positions, 4 waves
     else if (n32 == 3) launch4<3, 1, 2>(a, g, w_wino4, s);       //  96 co x 256 positions, 4 waves
     else launch4<2, 2, 2>(a, g, w_wino4, s);                     // 128 co x 256 positions, 8 waves
     BABE_LAUNCH_CHECK();
