@@ -35,7 +35,10 @@ struct Wino4pGeom {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr unsigned OOB = 0x80000000u;      // beyond every descriptor's num_records: the load returns 0, touches nothing
 
-template <int NTW, int WR, int WC, bool HAS_ISC>
+// XSOA: the transformed activations are stored phase-planar, [triple][ci][phase][unit] floats (12 bytes per unit and
+// triple instead of a padded float4), and a B operand is three ds_read_b32: 24 KB instead of 32 KB per slab for 128 units,
+// which is what lets the 96-channel tile (96 co x 512 positions) keep three buffers inside 160 KB of LDS.
+template <int NTW, int WR, int WC, bool HAS_ISC, bool XSOA = false>
 __global__ __launch_bounds__(128 * WR * WC, 1) void conv_wino4p_kernel(babe_conv_args a, Wino4pGeom g,
                                                                        const float* __restrict__ wq) {
 #if __HIP_DEVICE_COMPILE__      // the buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(128 * WR * WC, 1) void conv_wino4p_kernel(babe_conv
     constexpr int NW4 = 2 * KC * BN;                    // weight float4 per slab
     static_assert(NW4 % NTH == 0, "weight slab = whole wave instructions");
     constexpr int WJ = NW4 / NTH;
-    constexpr int XSZ = 2 * KC * NUNIT;                 // float4 units
+    constexpr int XSZ = XSOA ? 2 * KC * 3 * NUNIT / 4 : 2 * KC * NUNIT;      // float4 units
     constexpr int BUF = XSZ + NW4;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     f32x4* smem = reinterpret_cast<f32x4*>(smem_f);
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(128 * WR * WC, 1) void conv_wino4p_kernel(babe_conv
         xcolbad[v] = t < a.T ? 0u : OOB;
         xleftbad[v] = (t < a.T && t > 0) ? 0u : OOB;
         xrightbad[v] = t + 4 < a.T ? 0u : OOB;
-        xlds[v] = ci * NUNIT + (row << upr_log2) + i4;
+        xlds[v] = XSOA ? ci * 3 * NUNIT + (row << upr_log2) + i4 : ci * NUNIT + (row << upr_log2) + i4;
     }
     int wvo[WJ];                       // byte offset of this thread's float4 inside a weight slab, and its LDS slot
 #pragma unroll
@@ -162,8 +165,18 @@ __global__ __launch_bounds__(128 * WR * WC, 1) void conv_wino4p_kernel(babe_conv
             }
             const float e = d4 - 4.f * d2, o = d3 - 4.f * d1;        // shared by U1/U2
             const float e2 = d4 - d2, o2 = 2.f * (d3 - d1);          // shared by U3/U4
-            buf[xlds[v]] = f32x4{4.f * d0 - 5.f * d2 + d4, e + o, e - o, 0.f};
-            buf[KC * NUNIT + xlds[v]] = f32x4{e2 + o2, e2 - o2, 4.f * d1 - 5.f * d3 + d5, 0.f};
+            if (XSOA) {
+                float* xf = reinterpret_cast<float*>(buf) + xlds[v];
+                xf[0] = 4.f * d0 - 5.f * d2 + d4;
+                xf[NUNIT] = e + o;
+                xf[2 * NUNIT] = e - o;
+                xf[KC * 3 * NUNIT] = e2 + o2;
+                xf[KC * 3 * NUNIT + NUNIT] = e2 - o2;
+                xf[KC * 3 * NUNIT + 2 * NUNIT] = 4.f * d1 - 5.f * d3 + d5;
+            } else {
+                buf[xlds[v]] = f32x4{4.f * d0 - 5.f * d2 + d4, e + o, e - o, 0.f};
+                buf[KC * NUNIT + xlds[v]] = f32x4{e2 + o2, e2 - o2, 4.f * d1 - 5.f * d3 + d5, 0.f};
+            }
         }
     };
     auto dma_w = [&](int kh, int ci0, f32x4* buf, int j0, int j1) {
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(128 * WR * WC, 1) void conv_wino4p_kernel(babe_conv
         }
     };
 
-    const int boff = (tr * KC + h) * NUNIT + wc * 32 + l31;
+    const int boff = XSOA ? (tr * KC + h) * 3 * NUNIT + wc * 32 + l31 : (tr * KC + h) * NUNIT + wc * 32 + l31;
     const int aoff = XSZ + (tr * KC + h) * BN + wr * (NTW * 32) + l31;
 
     // ---- prologue: slabs 0 and 1 into buffers 0 and 1, loads of slab 2 in flight
@@ -206,7 +219,12 @@ __global__ __launch_bounds__(128 * WR * WC, 1) void conv_wino4p_kernel(babe_conv
     f32x4 av[2][NTW], bv[2];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) av[0][nt] = smem[aoff + nt * 32];
-    bv[0] = smem[boff];
+    if (XSOA) {
+        const float* xf = reinterpret_cast<const float*>(smem) + boff;
+        bv[0] = f32x4{xf[0], xf[NUNIT], xf[2 * NUNIT], 0.f};
+    } else {
+        bv[0] = smem[boff];
+    }
 
     int rb = 0;                                   // ring slot of the slab being multiplied
     for (int j = 0; j < nslab; ++j) {
@@ -220,7 +238,12 @@ __global__ __launch_bounds__(128 * WR * WC, 1) void conv_wino4p_kernel(babe_conv
         acc[nt][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][nt][p], bv[c][p], acc[nt][p], 0, 0, 0);
 #define READ_STEP(c, base, st)                                                                              \
     _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) av[c][nt] = (base)[aoff + 2 * (st) * BN + nt * 32];  \
-    bv[c] = (base)[boff + 2 * (st) * NUNIT];
+    if (XSOA) {                                                                                             \
+        const float* xf_ = reinterpret_cast<const float*>(base) + boff + 2 * (st) * 3 * NUNIT;              \
+        bv[c] = f32x4{xf_[0], xf_[NUNIT], xf_[2 * NUNIT], 0.f};                                             \
+    } else {                                                                                                \
+        bv[c] = (base)[boff + 2 * (st) * NUNIT];                                                            \
+    }
         // K-step 0: transform + write the staged activations of slab j+2, re-issue the staging loads (slab j+3), first
         // half of the weight DMA of slab j+2 (issued early: it has to land before the barrier at the end of this slab)
         READ_STEP(1, Xs, 1)
@@ -327,7 +350,7 @@ inline int ilog2_ceil_p(int v) {
     return l;
 }
 
-template <int NTW, int WR, int WC>
+template <int NTW, int WR, int WC, bool XSOA = false>
 void launch4p(const babe_conv_args& a, Wino4pGeom g, const float* wq, hipStream_t s) {
     constexpr int NPOS = 128 * WC;
     const int npos_log2 = ilog2_floor_p(NPOS);
@@ -340,21 +363,21 @@ void launch4p(const babe_conv_args& a, Wino4pGeom g, const float* wq, hipStream_
     const int tiles_f = cdiv(a.F, PR);
     constexpr int BN = WR * NTW * 32;
     dim3 grid(g.tiles_t * tiles_f, g.CoutP / BN, a.B);
-    size_t lds = 3 * (size_t)(2 * 8 * (WC * 32) + 2 * 8 * BN) * 16;
+    size_t lds = 3 * (size_t)((XSOA ? 2 * 8 * 3 * (WC * 32) / 4 : 2 * 8 * (WC * 32)) + 2 * 8 * BN) * 16;
     const size_t ex = (size_t)WR * WC * 3072 * 4;
     if (ex > lds) lds = ex;
     static bool attr_done = false;
     if (!attr_done) {                       // 144 KB of dynamic LDS: above the 64 KB default cap
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4p_kernel<NTW, WR, WC, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4p_kernel<NTW, WR, WC, true, XSOA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4p_kernel<NTW, WR, WC, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4p_kernel<NTW, WR, WC, false, XSOA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     if (a.in_scale)
-        hipLaunchKernelGGL((conv_wino4p_kernel<NTW, WR, WC, true>), grid, dim3(128 * WR * WC), lds, s, a, g, wq);
+        hipLaunchKernelGGL((conv_wino4p_kernel<NTW, WR, WC, true, XSOA>), grid, dim3(128 * WR * WC), lds, s, a, g, wq);
     else
-        hipLaunchKernelGGL((conv_wino4p_kernel<NTW, WR, WC, false>), grid, dim3(128 * WR * WC), lds, s, a, g, wq);
+        hipLaunchKernelGGL((conv_wino4p_kernel<NTW, WR, WC, false, XSOA>), grid, dim3(128 * WR * WC), lds, s, a, g, wq);
 }
 
 }  // namespace
@@ -364,7 +387,7 @@ int babe_conv2d_wino4p_supported(const babe_conv_args& a) {
     static const char* ov = getenv("BABE_CONV_WINO4P");
     if (ov && ov[0] == '0') return 0;
     const int n32 = (a.Cout + 31) / 32;
-    if (n32 % 4 != 0) return 0;                                         // 128-channel row blocks (8-wave workgroups)
+    if (n32 % 4 != 0 && n32 != 2 && n32 != 3) return 0;   // 8-wave workgroups: 128 co x 256 pos, 64 / 96 co x 512 pos
     if (a.in2 && (a.cin_split % 8 != 0)) return 0;
     const long lim = 0x7fffffffL / 4;
     const int split = a.in2 ? a.cin_split : a.Cin;
@@ -378,6 +401,8 @@ int babe_conv2d_wino4p_launch(const babe_conv_args& a, const float* w_wino4, hip
     Wino4pGeom g;
     g.CinP = (a.Cin + 7) / 8 * 8;
     g.CoutP = (a.Cout + 31) / 32 * 32;
-    launch4p<2, 2, 2>(a, g, w_wino4, s);                                // 128 co x 256 positions, 8 waves
+    if (g.CoutP == 64) launch4p<2, 1, 4>(a, g, w_wino4, s);             //  64 co x 512 positions, 8 waves
+    else if (g.CoutP == 96) launch4p<3, 1, 4, true>(a, g, w_wino4, s);  //  96 co x 512 positions, phase-planar activations
+    else launch4p<2, 2, 2>(a, g, w_wino4, s);                           // 128 co x 256 positions, 8 waves
     return 0;
 }
