@@ -16,6 +16,7 @@ Every linear map has its exact adjoint (same kernels, other window table), used 
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -116,6 +117,7 @@ class _BandsStruct(C.Structure):
                 ("c", C.c_void_p), ("M", C.c_void_p), ("woff", C.c_void_p), ("log2T", C.c_void_p),
                 ("oct", C.c_void_p), ("binoct", C.c_void_p), ("tw4096", C.c_void_p),
                 ("nocts", C.c_int), ("binsoct", C.c_int), ("coef", C.c_void_p * 8),
+                ("wg_first", C.c_void_p), ("wg_count", C.c_void_p), ("nwg", C.c_int), ("abl", C.c_int),
                 ("sum_T", C.c_long), ("sum_M", C.c_long), ("sum_TlogT", C.c_double)]
 
 
@@ -227,6 +229,15 @@ class CQT_nsgt:
         self.T_oct = [int(d["T"][j * binsoct]) for j in range(numocts)]
         self._tabs = dict(c=ti(d["c"]), M=ti(d["M"]), woff=ti(d["woff"]), log2T=ti(np.log2(d["T"]).astype(np.int64)),
                           oct=ti(np.arange(d["nb"]) // binsoct), binoct=ti(np.arange(d["nb"]) % binsoct))
+        # workgroup table of the band-FFT kernels: 4096 points (4096/T bands of one octave, at most the whole octave) each
+        wgf, wgc = [], []
+        for j in range(numocts):
+            bpw = int(min(binsoct, max(1, 4096 // self.T_oct[j])))
+            for s0 in range(0, binsoct, bpw):
+                wgf.append(j * binsoct + s0)
+                wgc.append(min(bpw, binsoct - s0))
+        self._tabs["wg_first"], self._tabs["wg_count"] = ti(wgf), ti(wgc)
+        self.nwg = len(wgf)
         q = np.arange(2048, dtype=np.float64)
         self.tw4096 = tf(np.stack([np.cos(2 * np.pi * q / 4096), -np.sin(2 * np.pi * q / 4096)], -1)).contiguous()
         g, gd, Tw = d["g"], d["gdual"], d["Tw"]
@@ -248,8 +259,10 @@ class CQT_nsgt:
         s = _BandsStruct()
         d = self.design
         s.nbands, s.L, s.KX = d["nb"], self.Ls, self.fft.KX
-        for k in ("c", "M", "woff", "log2T", "oct", "binoct"):
+        for k in ("c", "M", "woff", "log2T", "oct", "binoct", "wg_first", "wg_count"):
             setattr(s, k, ptr(self._tabs[k]))
+        s.nwg = self.nwg
+        s.abl = int(os.environ.get("BABE_CQT_ABL", "0"))
         s.tw4096 = ptr(self.tw4096)
         s.nocts, s.binsoct = self.numocts, self.binsoct
         s.sum_T, s.sum_M = int(np.sum(d["T"])), int(np.sum(d["M"]))

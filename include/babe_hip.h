@@ -132,6 +132,10 @@ typedef struct {
     const float* tw4096; /* [2048] float2 exp(-2 pi i q/4096)                 */
     int nocts; int binsoct;
     float* coef[8];      /* per octave planar [B][2][binsoct][T_oct]          */
+    /* workgroup table: workgroup w transforms bands wg_first[w] .. wg_first[w]+wg_count[w]-1, all of one octave
+     * (same T), wg_count[w] * T <= 4096 points */
+    const int* wg_first; const int* wg_count; int nwg;
+    int abl;             /* timing-only ablation bits (1: skip the FFT passes); 0 in production */
     long sum_T, sum_M;   /* sum over bands of T_k and M_k (for the measurement hook's algorithmic bytes) */
     double sum_TlogT;    /* sum over bands of T_k*log2(T_k) (algorithmic FFT flops = 5*that)            */
 } babe_cqt_bands;
