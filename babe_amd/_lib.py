@@ -34,6 +34,8 @@ _P, _L, _I, _F = C.c_void_p, C.c_long, C.c_int, C.c_float
 _SIGS = {
     "babe_conv2d": [C.POINTER(ConvArgs), _P],
     "babe_conv_pack_weights": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "babe_conv2d_nt": [C.POINTER(ConvArgs), _I, _P],
+    "babe_conv_pack_weights_nt": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "babe_conv2d_bf16": [C.POINTER(ConvArgs), _P, _I, _P],
     "babe_conv2d_wino": [C.POINTER(ConvArgs), _P, _P],
     "babe_conv2d_wino_supported": [C.POINTER(ConvArgs)],

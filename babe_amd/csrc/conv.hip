@@ -427,18 +427,26 @@ extern "C" long babe_conv_packed_size(int Cout, int Cin, int KH, int KW, int tra
 
 extern "C" int babe_conv_pack_weights(const float* w, float* dst, int Cout, int Cin, int KH, int KW,
                                       int transpose_flip, void* stream) {
+    return babe_conv_pack_weights_nt(w, dst, Cout, Cin, KH, KW, transpose_flip, 0, stream);
+}
+
+extern "C" int babe_conv_pack_weights_nt(const float* w, float* dst, int Cout, int Cin, int KH, int KW,
+                                         int transpose_flip, int nt, void* stream) {
     BABE_CHECK_ARG(w && dst && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "conv_pack_weights: bad arguments");
     const int co = transpose_flip ? Cin : Cout;
     const int ci = transpose_flip ? Cout : Cin;
     const int CinP = (ci + 7) / 8 * 8, CoutP = (co + 31) / 32 * 32;
     const long total = (long)KH * KW * CinP * CoutP;
+    BABE_CHECK_ARG(nt == 0 || (nt >= 1 && nt <= 4 && (CoutP / 32) % nt == 0), "conv_pack_weights_nt: nt=%d does not divide %d row tiles", nt, CoutP / 32);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout,
-                       Cin, KH, KW, transpose_flip, CinP, CoutP, total, pick_nt(CoutP));
+                       Cin, KH, KW, transpose_flip, CinP, CoutP, total, nt > 0 ? nt : pick_nt(CoutP));
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }
 
-extern "C" int babe_conv2d(const babe_conv_args* ap, void* stream) {
+extern "C" int babe_conv2d(const babe_conv_args* ap, void* stream) { return babe_conv2d_nt(ap, 0, stream); }
+
+extern "C" int babe_conv2d_nt(const babe_conv_args* ap, int nt, void* stream) {
     BABE_CHECK_ARG(ap, "conv2d: null args");
     const babe_conv_args& a = *ap;
     BABE_CHECK_ARG(a.in && a.w_packed && a.out, "conv2d: null pointer");
@@ -450,7 +458,8 @@ extern "C" int babe_conv2d(const babe_conv_args* ap, void* stream) {
     g.CinP = (a.Cin + 7) / 8 * 8;
     g.CoutP = (a.Cout + 31) / 32 * 32;
     const int n32 = g.CoutP / 32;
-    const int NT = pick_nt(g.CoutP);
+    const int NT = nt > 0 ? nt : pick_nt(g.CoutP);
+    BABE_CHECK_ARG(NT >= 1 && NT <= 4 && n32 % NT == 0, "conv2d_nt: nt=%d does not divide %d row tiles", NT, n32);
     // positions per block: measured on MI355X (tools/conv_shapes_bench.py) 128-position blocks (WP=1, 3-4 blocks/CU)
     // beat 256-position blocks (2/CU) on every wide layer because partial last rounds are cheaper; the
     // 64-channel layers (NT<=2) run equally fast with either, so they keep the larger tile.

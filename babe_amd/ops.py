@@ -30,8 +30,10 @@ class PackedConv:
     """Conv2d weights packed for babe_conv2d, forward and input-VJP (flipped/transposed) versions.
     precision: 'f32' (exact fp32 MFMA), 'bf16' or 'bf16x3' (bf16 MFMA, see csrc/conv_bf16.hip)."""
 
-    def __init__(self, w, precision="f32"):
+    def __init__(self, w, precision="f32", nt=0):
+        """nt: row tiles (x32 output channels) per workgroup of the direct kernel, 0 = default (include/babe_hip.h)."""
         self.precision = precision
+        self.nt = nt
         self.splits = PRECISIONS[precision]
         if self.splits:
             self._init_bf16(w)
@@ -60,8 +62,8 @@ class PackedConv:
         nb = L.babe_conv_packed_size(self.Cout, self.Cin, self.KH, self.KW, 1)
         self.fwd = torch.empty(nf, device=w.device, dtype=torch.float32)
         self.bwd = torch.empty(nb, device=w.device, dtype=torch.float32)
-        check(L.babe_conv_pack_weights(ptr(w), ptr(self.fwd), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack")
-        check(L.babe_conv_pack_weights(ptr(w), ptr(self.bwd), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack")
+        check(L.babe_conv_pack_weights_nt(ptr(w), ptr(self.fwd), self.Cout, self.Cin, self.KH, self.KW, 0, self.nt, stream()), "pack")
+        check(L.babe_conv_pack_weights_nt(ptr(w), ptr(self.bwd), self.Cout, self.Cin, self.KH, self.KW, 1, self.nt, stream()), "pack")
         # Winograd F(2,3)-along-time images for the 3-tap kernels (used whenever the problem qualifies)
         self.fwd_wino = self.bwd_wino = None
         if self.KW == 3 and WINOGRAD:
@@ -116,7 +118,7 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
     elif getattr(pc, "fwd_wino", None) is not None and lib().babe_conv2d_wino_supported(C.byref(a)):
         check(lib().babe_conv2d_wino(C.byref(a), ptr(pc.bwd_wino if transpose else pc.fwd_wino), stream()), "conv2d_wino")
     else:
-        check(lib().babe_conv2d(C.byref(a), stream()), "conv2d")
+        check(lib().babe_conv2d_nt(C.byref(a), pc.nt, stream()), "conv2d")
     return out
 
 

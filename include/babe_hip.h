@@ -41,6 +41,13 @@ int babe_conv2d(const babe_conv_args* a, void* stream);
 int babe_conv_pack_weights(const float* w, float* dst, int Cout, int Cin, int KH, int KW,
                            int transpose_flip, void* stream);
 long babe_conv_packed_size(int Cout, int Cin, int KH, int KW, int transpose_flip);
+/* Same with an explicit row-tile count per workgroup (nt x 32 output channels; 0 = the default, the largest of 4..1 that
+ * divides ceil32(Cout)/32).  nt = 1 gives the most workgroups: used for the dense DFT stages of the length-L real FFT,
+ * whose "positions" are only a few hundred (networks/cqtdiff+.py:743 -> CQT_nsgt.fwd -> torch.fft).  Weights packed with
+ * a given nt must be used with the same nt. */
+int babe_conv2d_nt(const babe_conv_args* a, int nt, void* stream);
+int babe_conv_pack_weights_nt(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip, int nt,
+                              void* stream);
 /* bf16-MFMA variants (fp32 tensors in HBM, bf16 operands, fp32 accumulate): splits=1 plain bf16 (configs #3-#5),
  * splits=2 "bf16x3" (hi/lo split of both operands, three products: 16-bit-mantissa multiplies).
  * w_bf16 from babe_conv_pack_weights_bf16: [splits][KH][KW][ceil16(Cin)/8][ceil32(Cout)][8] bf16. */
