@@ -1,0 +1,235 @@
+// (1,1) Conv2d (proj_in / proj_out / res_conv and the k=(1,1) init / out ResnetBlocks of networks/cqtdiff+.py:412-415,
+// 675, 690, 719; the same with transposed weights for the input-VJP) as a PIPELINED fp32-MFMA GEMM, round 2.
+//
+// These convs are 8.7 % of the benchmark's kernel time and sit between the two roofs: 2*Cin*Cout flops per position
+// against 4*(Cin+Cout) bytes is 16-40 flop/B for the UNet's channel counts, i.e. 40-60 us of HBM time and about as much
+// fp32-MFMA time per launch, where the generic direct kernel (8-channel slabs, one barrier each, register staging) took
+// 80-240 us (2.2-2.8 TB/s algorithmic).  A (1,1) conv needs no halo, no taps and no transform, so BOTH operands travel
+// global -> LDS by LDS-DMA through buffer descriptors (zero padding of ragged tiles / padded channels = the hardware range
+// check) with no staging registers at all:
+//   workgroup = 4 waves, 256 positions x BN = NT*32 output channels (the tile the weights were packed for);
+//   K-slab = 16 input channels: X [16][256] floats + W [16][BN] floats, ring of THREE buffers, slab j+2 in flight while
+//   slab j is multiplied, first operands of slab j+1 read before the barrier that ends slab j (as conv_wino4p.hip);
+//   wave = 64 positions (2 MFMA column tiles) x all NT row tiles: per K-step NT floats of A (one 4/8/16-byte LDS read) and
+//   2 of B feed 2*NT v_mfma_f32_32x32x2_f32; in_scale (the VJP's gate) multiplies the A fragment.
+// Packed weights and epilogue are those of conv.hip (conv_common.h).  Requirements: KH = KW = 1, T % 4 == 0, 16-byte
+// aligned views, cin_split % 16 == 0, views below 2 GiB; anything else stays on the generic kernel.
+#include "common.h"
+#include "../../include/babe_hip.h"
+#include "prof.h"
+#include "conv_common.h"
+#include <cstdlib>
+
+namespace {
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr unsigned OOB11 = 0x80000000u;
+
+struct C11Geom {
+    int CinP, CoutP, pt_log2, pr_log2, tiles_t;
+};
+
+// NPW = 32-position MFMA column tiles per wave: 2 (256 positions per workgroup, 2 workgroups per CU) or 1 (128 positions,
+// 3 per CU: finer tail quantisation for the launches with only a few hundred workgroups)
+template <int NT, int NPW, bool HAS_ISC>
+__global__ __launch_bounds__(256, NPW == 2 ? 2 : 3) void conv11p_kernel(babe_conv_args a, C11Geom g) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int KC = 16;
+    constexpr int BN = NT * 32;
+    constexpr int NPOS = 128 * NPW;
+    constexpr int XF = KC * NPOS;                       // floats of X per slab
+    constexpr int XJ = XF / 4 / 256;                    // DMA instructions per thread for X (4 or 2)
+    constexpr int Q4 = NPOS / 4;                        // float4 per channel row
+    constexpr int WF4 = KC * BN / 4;                    // float4 of W per slab
+    constexpr int WJ = (WF4 + 255) / 256;
+    constexpr int BUF = XF + WJ * 256 * 4;              // floats per ring slot
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int PT = 1 << g.pt_log2;
+    const int tile_t = blockIdx.x % g.tiles_t;
+    const int tile_f = blockIdx.x / g.tiles_t;
+    const int t0 = tile_t << g.pt_log2;
+    const int f0 = tile_f << g.pr_log2;
+    const int co0 = blockIdx.y * BN;
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int l31 = lane & 31;
+    const int split = a.in2 ? a.cin_split : a.Cin;
+
+    const float* p1 = a.in + (long)b * a.in_bs;
+    const float* p2 = a.in2 ? a.in2 + (long)b * a.in2_bs : p1;
+    const int cs1 = (int)a.in_cs, cs2 = a.in2 ? (int)a.in2_cs : (int)a.in_cs;
+    const int nb1 = split * cs1 * 4, nb2 = (a.Cin - split) * cs2 * 4;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_packed, 0, g.CinP * g.CoutP * 4, 0x00020000);
+
+    // per-thread DMA offsets: X piece v = float4 q of channel row ci_l;  W piece jj = float4 c4 of row ci_l
+    int xoff1[XJ], xoff2[XJ];
+    unsigned xbad[XJ];
+#pragma unroll
+    for (int v = 0; v < XJ; ++v) {
+        const int idx = tid + v * 256;
+        const int ci_l = idx / Q4;
+        const int p = (idx % Q4) * 4;
+        const int f = f0 + (p >> g.pt_log2), t = t0 + (p & (PT - 1));
+        xbad[v] = (f < a.F && t < a.T) ? 0u : OOB11;
+        xoff1[v] = (ci_l * cs1 + f * a.T + t) * 4;
+        xoff2[v] = (ci_l * cs2 + f * a.T + t) * 4;
+    }
+    unsigned woff[WJ];
+#pragma unroll
+    for (int jj = 0; jj < WJ; ++jj) {
+        const int idx = tid + jj * 256;
+        const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+        woff[jj] = idx < WF4 ? (unsigned)((row * g.CoutP + co0 + c4 * 4) * 4) : OOB11;
+    }
+    auto dma_slab = [&](int ci0, float* buf) {
+        const bool s2 = ci0 >= split;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(s2 ? p2 : p1), 0, s2 ? nb2 : nb1, 0x00020000);
+        const int so = (s2 ? (ci0 - split) * cs2 : ci0 * cs1) * 4;
+#pragma unroll
+        for (int v = 0; v < XJ; ++v)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(buf + (v * 256 + wave * 64) * 4), 16,
+                                                     (unsigned)((s2 ? xoff2[v] : xoff1[v]) + so) | xbad[v], 0, 0, 0);
+#pragma unroll
+        // (the whole offset is in the VGPR operand: the range check that zero-fills rows >= CinP covers only that one)
+        for (int jj = 0; jj < WJ; ++jj)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(buf + XF + (jj * 256 + wave * 64) * 4), 16,
+                                                     woff[jj] + (unsigned)(ci0 * g.CoutP * 4), 0, 0, 0);
+    };
+
+    f32x16 acc[NT][NPW];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NPW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nslab = (g.CinP + KC - 1) / KC;
+    const int boff = h * NPOS + wave * (32 * NPW) + l31;
+    const int aoff = XF + h * BN + l31 * NT;
+    const float* isp = HAS_ISC ? a.in_scale + (long)b * a.Cin : nullptr;
+
+    // prologue: slabs 0 and 1 (a slab index beyond the last one is clamped: re-staged, never read)
+    dma_slab(0, smem);
+    dma_slab(nslab > 1 ? KC : 0, smem + BUF);
+    __syncthreads();
+
+    float av[2][NT], bv[2][NPW];
+    AVec<NT>::ld(smem + aoff, av[0]);
+#pragma unroll
+    for (int wp = 0; wp < NPW; ++wp) bv[0][wp] = smem[boff + 32 * wp];
+
+    int rb = 0;
+    for (int j = 0; j < nslab; ++j) {
+        const int rn = rb == 2 ? 0 : rb + 1;
+        const int rw = rn == 2 ? 0 : rn + 1;
+        const float* Xs = smem + rb * BUF;
+        const float* Xn = smem + rn * BUF;
+        const int jw = j + 2 < nslab ? j + 2 : nslab - 1;
+        dma_slab(jw * KC, smem + rw * BUF);
+        const int ci0 = j * KC;
+#pragma unroll
+        for (int st = 0; st < KC / 2; ++st) {
+            const int c = st & 1;
+            if (st + 1 < KC / 2) {
+                AVec<NT>::ld(Xs + aoff + 2 * (st + 1) * BN, av[c ^ 1]);
+#pragma unroll
+                for (int wp = 0; wp < NPW; ++wp) bv[c ^ 1][wp] = Xs[boff + 2 * (st + 1) * NPOS + 32 * wp];
+            } else {
+                AVec<NT>::ld(Xn + aoff, av[c ^ 1]);          // first operands of slab j+1, before the barrier
+#pragma unroll
+                for (int wp = 0; wp < NPW; ++wp) bv[c ^ 1][wp] = Xn[boff + 32 * wp];
+            }
+            if (HAS_ISC) {
+                // in_scale of channels ci0 + 2 st (+1): wave-uniform scalar loads, selected by the lane's k index
+                const int c0 = ci0 + 2 * st, c1 = c0 + 1;
+                const float s0 = isp[c0 < a.Cin ? c0 : a.Cin - 1], s1 = isp[c1 < a.Cin ? c1 : a.Cin - 1];
+                const float sc = h ? s1 : s0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) av[c][nt] *= sc;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int wp = 0; wp < NPW; ++wp)
+                    acc[nt][wp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][nt], bv[c][wp], acc[nt][wp], 0, 0, 0);
+        }
+        __syncthreads();                                   // slab j+2 landed (vmcnt(0)), slab j's buffer free
+        rb = rn;
+    }
+    conv_epilogue<NT, NPW>(a, acc, b, co0, f0, t0, g.pt_log2, wave, l31, h);
+#endif
+}
+
+template <int NT, int NPW>
+void launch11(const babe_conv_args& a, C11Geom g, hipStream_t s) {
+    constexpr int LOGP = NPW == 2 ? 8 : 7;
+    g.pt_log2 = 0;
+    while ((1 << g.pt_log2) < a.T && g.pt_log2 < LOGP) ++g.pt_log2;
+    if (g.pt_log2 < 2) g.pt_log2 = 2;
+    g.pr_log2 = LOGP - g.pt_log2;
+    g.tiles_t = cdiv(a.T, 1 << g.pt_log2);
+    const int tiles_f = cdiv(a.F, 1 << g.pr_log2);
+    constexpr int BN = NT * 32;
+    constexpr int WJ = (16 * BN / 4 + 255) / 256;
+    const size_t lds = 3 * (size_t)(16 * 128 * NPW + WJ * 256 * 4) * 4;
+    dim3 grid(g.tiles_t * tiles_f, g.CoutP / BN, a.B);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv11p_kernel<NT, NPW, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv11p_kernel<NT, NPW, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (a.in_scale) hipLaunchKernelGGL((conv11p_kernel<NT, NPW, true>), grid, dim3(256), lds, s, a, g);
+    else hipLaunchKernelGGL((conv11p_kernel<NT, NPW, false>), grid, dim3(256), lds, s, a, g);
+}
+
+}  // namespace
+
+/* 1 if the pipelined (1,1) kernel takes this problem; nt = row tiles the weights were packed for */
+int babe_conv11p_supported(const babe_conv_args& a, int nt) {
+    static const char* ov = getenv("BABE_CONV11P");
+    if (ov && ov[0] == '0') return 0;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (a.KH != 1 || a.KW != 1 || a.T % 4 != 0 || nt < 1 || nt > 4) return 0;
+    if (!al16(a.in) || a.in_bs % 4 || a.in_cs % 4) return 0;
+    if (a.in2 && (!al16(a.in2) || a.in2_bs % 4 || a.in2_cs % 4 || a.cin_split % 16)) return 0;
+    if (!al16(a.w_packed)) return 0;
+    const long lim = 0x7fffffffL / 4;
+    const int split = a.in2 ? a.cin_split : a.Cin;
+    if ((long)split * a.in_cs >= lim || (a.in2 && (long)(a.Cin - split) * a.in2_cs >= lim)) return 0;
+    if ((long)((a.Cin + 7) / 8 * 8) * ((a.Cout + 31) / 32 * 32) >= lim) return 0;
+    if ((long)a.F * a.T < 4096) return 0;                    // tiny planes: nothing to pipeline
+    return 1;
+}
+
+int babe_conv11p_launch(const babe_conv_args& a, int nt, hipStream_t s) {
+    C11Geom g;
+    g.CinP = (a.Cin + 7) / 8 * 8;
+    g.CoutP = (a.Cout + 31) / 32 * 32;
+    // Tile choice by tail quantisation: a launch costs about rounds x (resident workgroups per CU x positions per
+    // workgroup); 128-position tiles run 3 per CU, 256-position tiles 2 per CU (measured: tools/conv_shapes_bench.py)
+    const long cot = g.CoutP / (nt * 32);
+    const long b128 = (((long)a.F * a.T + 127) / 128) * cot * a.B, b256 = (((long)a.F * a.T + 255) / 256) * cot * a.B;
+    const long cost1 = ((b128 + 767) / 768) * 3, cost2 = ((b256 + 511) / 512) * 4;
+    static const char* ov = getenv("BABE_CONV11P_NPW");
+    const bool big = ov ? ov[0] == '2' : cost2 < cost1;
+    switch (nt * 2 + (big ? 1 : 0)) {
+        case 9: launch11<4, 2>(a, g, s); break;
+        case 8: launch11<4, 1>(a, g, s); break;
+        case 7: launch11<3, 2>(a, g, s); break;
+        case 6: launch11<3, 1>(a, g, s); break;
+        case 5: launch11<2, 2>(a, g, s); break;
+        case 4: launch11<2, 1>(a, g, s); break;
+        case 3: launch11<1, 2>(a, g, s); break;
+        default: launch11<1, 1>(a, g, s); break;
+    }
+    return 0;
+}

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(128 * WR * WC, 1) void conv_wino4p_kernel(babe_conv
             xv[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, e | xcolbad[v], 0, 0));
             xl[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (e - 4u) | rowbad | xleftbad[v], 0, 0));
             xrr[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (e + 16u) | rowbad | xrightbad[v], 0, 0));
-            if (HAS_ISC) xsc[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, xci4[v], ci0 * 4, 0));
+            // (offset entirely in the VGPR operand: only that one is range-checked against Cin)
+            if (HAS_ISC) xsc[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, xci4[v] + ci0 * 4, 0, 0));
         }
     };
     auto store_act = [&](f32x4* buf) {

@@ -163,6 +163,42 @@ def test_conv2d_winograd_vs_direct_and_oracle(ops, B, C1, C2, Cout, Fq, T, dil):
     assert rel(gx[0], gref) < 2e-6 and rel(gx[0], gx[1]) < 2e-6 and rel(gx[2], gref) < 3e-6
 
 
+@pytest.mark.parametrize("B,C1,C2,Cout,Fq,T", [
+    (2, 64, 64, 96, 40, 128),      # two sources (decoder proj_in), 96 output channels (3 row tiles)
+    (1, 2, 0, 64, 64, 256),        # init block proj_in: 2 input channels (one zero-padded K-slab)
+    (2, 128, 0, 2, 33, 128),       # out block proj_out: 2 output channels, ragged F
+    (1, 72, 0, 256, 20, 272),      # Cin % 16 != 0 (last slab half empty), T not a power of two, two 128-channel tiles
+    (1, 256, 256, 128, 28, 64),    # decoder level 6: 512 -> 128, short rows (4 rows per tile)
+])
+def test_conv2d_1x1_pipelined_vs_oracle(ops, B, C1, C2, Cout, Fq, T):
+    """(1,1) convs on the pipelined DMA kernel (csrc/conv11p.hip): forward with the fused epilogue (oscale, residual into a
+    frequency sub-view) and the input-VJP with in_scale, vs float64."""
+    from babe_amd._lib import dispatch_counts
+    g = torch.Generator().manual_seed(C1 + Cout + T)
+    Cin = C1 + C2
+    x = torch.randn(B, Cin, Fq, T, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    res = torch.randn(B, Cout, Fq, T, generator=g)
+    osc = torch.randn(B, Cout, generator=g)
+    ref = 0.7 * UN.conv_same(x.double(), w.double()) * osc[:, :, None, None].double() + 0.3 * res.double()
+    pc = ops.PackedConv(w.cuda())
+    xc = x.cuda()
+    x1, x2 = (xc[:, :C1].contiguous(), xc[:, C1:].contiguous()) if C2 else (xc, None)
+    big = torch.zeros(B, Cout, 2 * Fq, T, device="cuda")
+    o = big[:, :, Fq:, :]
+    o.copy_(res.cuda())
+    ops.conv2d(x1, pc, o, x2=x2, res=o, oscale=osc.cuda(), alpha=0.7, rbeta=0.3)
+    assert float(big[:, :, :Fq, :].abs().max()) == 0.0
+    assert rel(o, ref) < 2e-6
+    gy = torch.randn(B, Cout, Fq, T, generator=g)
+    isc = torch.randn(B, Cout, generator=g)
+    gx = torch.empty(B, Cin, Fq, T, device="cuda")
+    ops.conv2d(gy.cuda(), pc, gx, transpose=True, in_scale=isc.cuda(), alpha=0.5)
+    xr = x.double().requires_grad_(True)
+    gref, = torch.autograd.grad((UN.conv_same(xr, w.double()) * (gy.double() * isc[:, :, None, None].double())).sum(), xr)
+    assert rel(gx, 0.5 * gref) < 2e-6
+
+
 def test_conv2d_winograd_dispatch_rules(ops):
     """Problems the Winograd kernel does not take (T % 4, misaligned views, 1x1) run on the direct kernel."""
     import ctypes as C
