@@ -118,6 +118,18 @@ __global__ __launch_bounds__(256, NPW == 2 ? 2 : 3) void conv11p_kernel(babe_con
     dma_slab(nslab > 1 ? KC : 0, smem + BUF);
     __syncthreads();
 
+    // in_scale of this lane's k index for the 8 K-steps of a slab, loaded one slab ahead (a scalar load inside the K-step
+    // would stall every step on its latency)
+    float scur[KC / 2], snext[KC / 2];
+    auto load_scales = [&](int ci0, float* dst) {
+#pragma unroll
+        for (int st = 0; st < KC / 2; ++st) {
+            const int c = ci0 + 2 * st + h;
+            dst[st] = HAS_ISC ? isp[c < a.Cin ? c : a.Cin - 1] : 1.f;
+        }
+    };
+    if (HAS_ISC) load_scales(0, scur);
+
     float av[2][NT], bv[2][NPW];
     AVec<NT>::ld(smem + aoff, av[0]);
 #pragma unroll
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(256, NPW == 2 ? 2 : 3) void conv11p_kernel(babe_con
         const float* Xn = smem + rn * BUF;
         const int jw = j + 2 < nslab ? j + 2 : nslab - 1;
         dma_slab(jw * KC, smem + rw * BUF);
-        const int ci0 = j * KC;
+        if (HAS_ISC) load_scales((j + 1 < nslab ? j + 1 : j) * KC, snext);
 #pragma unroll
         for (int st = 0; st < KC / 2; ++st) {
             const int c = st & 1;
@@ -145,12 +157,8 @@ __global__ __launch_bounds__(256, NPW == 2 ? 2 : 3) void conv11p_kernel(babe_con
                 for (int wp = 0; wp < NPW; ++wp) bv[c ^ 1][wp] = Xn[boff + 32 * wp];
             }
             if (HAS_ISC) {
-                // in_scale of channels ci0 + 2 st (+1): wave-uniform scalar loads, selected by the lane's k index
-                const int c0 = ci0 + 2 * st, c1 = c0 + 1;
-                const float s0 = isp[c0 < a.Cin ? c0 : a.Cin - 1], s1 = isp[c1 < a.Cin ? c1 : a.Cin - 1];
-                const float sc = h ? s1 : s0;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) av[c][nt] *= sc;
+                for (int nt = 0; nt < NT; ++nt) av[c][nt] *= scur[st];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -160,6 +168,10 @@ __global__ __launch_bounds__(256, NPW == 2 ? 2 : 3) void conv11p_kernel(babe_con
                     acc[nt][wp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][nt], bv[c][wp], acc[nt][wp], 0, 0, 0);
         }
         __syncthreads();                                   // slab j+2 landed (vmcnt(0)), slab j's buffer free
+        if (HAS_ISC) {
+#pragma unroll
+            for (int st = 0; st < KC / 2; ++st) scur[st] = snext[st];
+        }
         rb = rn;
     }
     conv_epilogue<NT, NPW>(a, acc, b, co0, f0, t0, g.pt_log2, wave, l31, h);

@@ -132,6 +132,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("babe_amd networks run on the GPU only (no CPU fallback); use device='cuda'")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         win = ("kaiser", nw.cqt.beta) if nw.cqt.window == "kaiser" else nw.cqt.window
         self.CQTransform = CQT_nsgt(self.num_octs, self.bins_per_oct, mode="oct", window=win,
                                     fs=args.exp.sample_rate, audio_len=args.exp.audio_len, device=self.device)
@@ -195,6 +197,11 @@ class Unet_CQT_oct_with_attention(nn.Module):
     # ---------------------------------------------------------------- raw (no autograd) interface
     def fwd_nograd(self, x, cnoise):
         """x [B,L], cnoise [B,1] -> [B,L]; keeps what vjp() needs until the next call."""
+        assert x.device == self.device, f"input on {x.device}, network on {self.device}"
+        with torch.cuda.device(self.device):       # every launch below goes to THIS device's current stream
+            return self._fwd_nograd(x, cnoise)
+
+    def _fwd_nograd(self, x, cnoise):
         eng = self.engine()
         x = x.detach().contiguous().float()
         assert x.shape[-1] == self.CQTransform.Ls, "input length must equal exp.audio_len (the CQT is built for it)"
@@ -210,6 +217,11 @@ class Unet_CQT_oct_with_attention(nn.Module):
 
     def vjp(self, g):
         """Gradient of <net(x), g> w.r.t. x for the last fwd_nograd call."""
+        assert g.device == self.device, f"gradient on {g.device}, network on {self.device}"
+        with torch.cuda.device(self.device):
+            return self._vjp(g)
+
+    def _vjp(self, g):
         eng = self.engine()
         gouts = self.CQTransform.bwd_adjoint(g.contiguous())
         B = g.shape[0]

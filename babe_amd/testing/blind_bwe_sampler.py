@@ -29,7 +29,13 @@ class BlindSampler:
     NBLK = 64
     SCORE_MODE = 0          # guidance scaling of blind_bwe_sampler.py:125-135
 
-    def __init__(self, model, diff_params, args, rid=False, batch_semantics="per_clip", noise_device="cpu"):
+    def __init__(self, model, diff_params, args, rid=False, batch_semantics="per_clip", noise_device="cpu",
+                 max_segments_in_flight=32):
+        """max_segments_in_flight: with per-clip semantics a larger batch is restored in sub-batches of at most this many
+        segments, one after the other (clips are independent; the UNet keeps 3.6 GB of activations per 368368-sample
+        segment between forward and VJP, so 32 in flight = 115 GB of the 288 GB).  Ignored for 'reference' semantics,
+        where the clips of a batch are coupled through the shared filter."""
+        self.max_in_flight = int(max_segments_in_flight)
         self.model = model
         self.diff_params = diff_params
         self.args = args
@@ -251,7 +257,12 @@ class BlindSampler:
         """y [B,L] observations on the GPU -> (x, filter_params[, data_denoised, t, data_filters])  (:619-769)."""
         if compute_sweep:
             raise NotImplementedError("compute_sweep (logging only)")
-        return self._sample(y, self._init_params(y.shape[0], y.device), blind=True, rid=rid)
+        B = y.shape[0]
+        if self.batch_semantics == "per_clip" and B > self.max_in_flight and not rid:
+            outs = [self._sample(y[i:i + self.max_in_flight], self._init_params(min(self.max_in_flight, B - i), y.device),
+                                 blind=True, rid=False) for i in range(0, B, self.max_in_flight)]
+            return torch.cat([o[0] for o in outs], 0), torch.cat([o[1].reshape(-1, *o[1].shape[-2:]) for o in outs], 0)
+        return self._sample(y, self._init_params(B, y.device), blind=True, rid=rid)
 
     def predict_bwe(self, ylpf, filt, filt_type, rid=False, test_filter_fit=False, compute_sweep=False):
         """Known-degradation variant (:306-364 -> predict_conditional :387-404 -> predict :406-498).

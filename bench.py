@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="conv arithmetic: f32 = exact fp32 MFMA (the benchmark's dtype); bf16x3 / bf16 = bf16 MFMA with "
                          "fp32 storage+accumulation (reported with their own dtype string, never as f32)")
-    ap.add_argument("--profile-steps", type=int, default=2,
+    ap.add_argument("--profile-steps", type=int, default=1,
                     help="timed steps whose launches are bracketed by HIP events (0 = no roofline/hbm blocks)")
     a = ap.parse_args()
 

@@ -32,14 +32,21 @@ for name, Cin, Cout, F, T, KH, KW, dil, cnt in shapes:
     w = torch.randn(Cout, Cin, KH, KW, device="cuda") / math.sqrt(Cin * KH * KW)
     pc = ops.PackedConv(w, os.environ.get('PRECISION', 'f32'))
     out = torch.empty(B, Cout, F, T, device="cuda")
+    VJP = os.environ.get("VJP") == "1"          # time the input-VJP form instead: transposed weights, in_scale (the gate)
+    if VJP:
+        x, out = out, torch.empty(B, Cin, F, T, device="cuda")
+        x.normal_()
+        kw = dict(dil=dil, transpose=True, in_scale=torch.randn(B, Cout, device="cuda"))
+    else:
+        kw = dict(dil=dil)
     for _ in range(2):
-        ops.conv2d(x, pc, out, dil=dil)
+        ops.conv2d(x, pc, out, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 5
     e0.record()
     for _ in range(n):
-        ops.conv2d(x, pc, out, dil=dil)
+        ops.conv2d(x, pc, out, **kw)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
