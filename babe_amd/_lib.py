@@ -35,6 +35,8 @@ _SIGS = {
     "babe_conv2d": [C.POINTER(ConvArgs), _P],
     "babe_conv_pack_weights": [_P, _P, _I, _I, _I, _I, _I, _P],
     "babe_conv2d_nt": [C.POINTER(ConvArgs), _I, _P],
+    "babe_conv2d_fewco": [C.POINTER(ConvArgs), _P, _I, _P],
+    "babe_conv2d_fewco_supported": [C.POINTER(ConvArgs)],
     "babe_conv_pack_weights_nt": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "babe_conv2d_bf16": [C.POINTER(ConvArgs), _P, _I, _P],
     "babe_conv2d_wino": [C.POINTER(ConvArgs), _P, _P],

@@ -218,7 +218,8 @@ int babe_conv11p_supported(const babe_conv_args& a, int nt) {
     const int split = a.in2 ? a.cin_split : a.Cin;
     if ((long)split * a.in_cs >= lim || (a.in2 && (long)(a.Cin - split) * a.in2_cs >= lim)) return 0;
     if ((long)((a.Cin + 7) / 8 * 8) * ((a.Cout + 31) / 32 * 32) >= lim) return 0;
-    if ((long)a.F * a.T < 4096) return 0;                    // tiny planes: nothing to pipeline
+    if ((long)a.F * a.T < 4096 && a.Cin < 256) return 0;     // tiny planes AND a short K loop: nothing to pipeline (the
+                                                             // dense DFT stages, K ~ 2000 over a few hundred positions, qualify)
     return 1;
 }
 

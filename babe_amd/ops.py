@@ -22,6 +22,7 @@ PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
 # debug switch for the (5,3) fp32 convs: 0 = direct kernel only, 2 = Winograd F(2,3) only, 4 (default) = F(4,3) where the
 # problem qualifies, F(2,3) otherwise
 _W = os.environ.get("BABE_CONV_WINO", "4")
+FEWCO = os.environ.get("BABE_CONV_FEWCO", "1") != "0"
 WINOGRAD = _W != "0"
 WINOGRAD4 = _W not in ("0", "2", "1")
 
@@ -57,6 +58,8 @@ class PackedConv:
         assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 4
         w = w.contiguous()
         self.Cout, self.Cin, self.KH, self.KW = w.shape
+        # raw weights for the few-output-channel kernel (the input-VJP of a 2..4-input-channel conv, csrc/conv_fewco.hip)
+        self.w_raw = w if (self.KW == 3 and min(self.Cout, self.Cin) <= 4) else None
         L = lib()
         nf = L.babe_conv_packed_size(self.Cout, self.Cin, self.KH, self.KW, 0)
         nb = L.babe_conv_packed_size(self.Cout, self.Cin, self.KH, self.KW, 1)
@@ -113,6 +116,8 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
     a.KH, a.KW, a.dil = pc.KH, pc.KW, dil
     if pc.splits:
         check(lib().babe_conv2d_bf16(C.byref(a), ptr(wq), pc.splits, stream()), "conv2d_bf16")
+    elif FEWCO and getattr(pc, "w_raw", None) is not None and Cout <= 4 and lib().babe_conv2d_fewco_supported(C.byref(a)):
+        check(lib().babe_conv2d_fewco(C.byref(a), ptr(pc.w_raw), int(transpose), stream()), "conv2d_fewco")
     elif getattr(pc, "fwd_wino4", None) is not None and lib().babe_conv2d_wino4_supported(C.byref(a)):
         check(lib().babe_conv2d_wino4(C.byref(a), ptr(pc.bwd_wino4 if transpose else pc.fwd_wino4), stream()), "conv2d_wino4")
     elif getattr(pc, "fwd_wino", None) is not None and lib().babe_conv2d_wino_supported(C.byref(a)):

@@ -154,7 +154,7 @@ def spawn_ranks(n):
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 HBM_SLOTS = ["conv11", "gn_stats", "scale_gelu", "gn_bwd_partial", "gn_bwd_apply", "resample", "axpby", "cqt_band_analysis",
              "cqt_band_synthesis", "cqt_gather", "stft_fwd", "istft", "mag_stats", "sampler"]
-CONV_SLOTS = ["conv53_wino4", "conv53_wino2", "conv53_direct", "conv11", "conv_bf16"]
+CONV_SLOTS = ["conv53_wino4", "conv53_wino2", "conv53_direct", "conv53_fewco", "conv11", "conv_bf16"]
 
 
 def slot_table(prof, names, wall_s=None):
@@ -363,7 +363,10 @@ def main():
             "value": round(value, 5), "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: one 10 s 44.1 kHz clip per GPU per step = 2 segments x 368368 samples, "
+            "config": {"workload": ("configs[1]: one 10 s 44.1 kHz clip per GPU per step = 2 segments x 368368 samples, "
+                                    if C_ == 1 else
+                                    "configs[2]-style batch: %d x 10 s 44.1 kHz clips per GPU per step (%d segments x 368368 "
+                                    "samples, restored in sub-batches of %d segments), " % (C_, C_ * nseg, sampler.max_in_flight)) +
                                    "blind LPF estimation, T=%d EDM steps (order 2, %d score evaluations), %s, "
                                    "CQTDiff+ Ns=[64,96,96,128,128,256,256], random-init weights" % (a.T, 2 * a.T - 1, a.precision),
                        "segments_per_clip": nseg, "clips_per_gpu_per_step": C_, "segment_len": SEG, "sample_rate": FS, "T": a.T,

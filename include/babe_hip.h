@@ -72,6 +72,12 @@ int babe_conv2d_wino4_supported(const babe_conv_args* a);
 int babe_conv_pack_weights_wino4(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
                                  void* stream);
 long babe_conv_packed_size_wino4(int Cout, int Cin, int KH, int transpose_flip);
+/* (KH,3) conv with at most 4 OUTPUT channels on the vector ALU (csrc/conv_fewco.hip): the input-VJP of the UNet's 2-channel
+ * pyramid projections (cqtdiff+.py:676, 794).  w is in the REFERENCE layout, not packed: [Cout][Cin][KH][3] for
+ * transpose_flip = 0; for transpose_flip = 1 the weights [Cin][Cout][KH][3] of the conv whose input-VJP is computed (a->Cin,
+ * a->Cout describe the op as executed).  One source, no in_scale. */
+int babe_conv2d_fewco(const babe_conv_args* a, const float* w, int transpose_flip, void* stream);
+int babe_conv2d_fewco_supported(const babe_conv_args* a);
 /* Measurement hook (bench.py; csrc/prof.h lists the slots): when enabled EVERY entry point of this library brackets
  * its launch with HIP events on the launch stream and tallies, per slot, the kernel time, the ALGORITHMIC bytes and flops
  * (conv: 2*B*Cout*Cin*KH*KW*F*T with the unpadded channel counts) and the flops the matrix pipe executes (Winograd

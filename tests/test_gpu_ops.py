@@ -199,6 +199,25 @@ def test_conv2d_1x1_pipelined_vs_oracle(ops, B, C1, C2, Cout, Fq, T):
     assert rel(gx, 0.5 * gref) < 2e-6
 
 
+@pytest.mark.parametrize("B,N,Fq,T,dil", [(2, 64, 40, 64, 1), (1, 96, 33, 128, 4), (1, 256, 16, 16, 2)])
+def test_conv2d_few_output_channels_vjp_of_pyramid_projection(ops, B, N, Fq, T, dil):
+    """Input-VJP of Conv2d(2 -> N, (5,3)) (the pyramid projections): 2 output channels on the vector-ALU kernel
+    (csrc/conv_fewco.hip), with alpha and an accumulated residual, vs float64 autograd."""
+    from babe_amd._lib import dispatch_counts
+    g = torch.Generator().manual_seed(N + T)
+    w = torch.randn(N, 2, 5, 3, generator=g) / math.sqrt(30)
+    pc = ops.PackedConv(w.cuda())
+    gy = torch.randn(B, N, Fq, T, generator=g)
+    acc = torch.randn(B, 2, Fq, T, generator=g)
+    x = torch.zeros(B, 2, Fq, T, dtype=torch.float64, requires_grad=True)
+    gref, = torch.autograd.grad((UN.conv_same(x, w.double(), dil) * gy.double()).sum(), x)
+    out = acc.cuda().clone()
+    dispatch_counts(reset=True)
+    ops.conv2d(gy.cuda(), pc, out, dil=dil, transpose=True, alpha=0.7, res=out, rbeta=1.0)
+    assert dispatch_counts()["conv53_fewco"] == 1
+    assert rel(out, 0.7 * gref + acc.double()) < 2e-6
+
+
 def test_conv2d_winograd_dispatch_rules(ops):
     """Problems the Winograd kernel does not take (T % 4, misaligned views, 1x1) run on the direct kernel."""
     import ctypes as C

@@ -82,9 +82,9 @@ def test_full_width_L368368_vs_reference_golden_all_wino4():
     assert ey < TOL_FWD and eg < TOL_VJP
     # forward: 75 dilated ResnetBlock convs + 7 pyramid projections, all on conv_wino4_kernel
     assert cf["conv53_wino4"] == 82 and cf["conv53_wino2"] == 0 and cf["conv53_direct"] == 0, cf
-    # VJP: the 75 dilated convs on F(4,3); the 7 pyramid projections transposed have 2 output channels (one 32-channel
-    # MFMA row tile), which only the F(2,3) kernel tiles
-    assert cb["conv53_wino4"] == 75 and cb["conv53_wino2"] == 7 and cb["conv53_direct"] == 0, cb
+    # VJP: the 75 dilated convs on F(4,3); the 7 pyramid projections transposed have 2 output channels and run on the
+    # vector-ALU kernel (csrc/conv_fewco.hip)
+    assert cb["conv53_wino4"] == 75 and cb["conv53_fewco"] == 7 and cb["conv53_wino2"] == 0 and cb["conv53_direct"] == 0, cb
     assert cf["conv_bf16"] == 0 and cb["conv_bf16"] == 0
 
 
