@@ -195,13 +195,32 @@ class Unet_CQT_oct_with_attention(nn.Module):
         return super()._apply(fn, *a, **k)
 
     # ---------------------------------------------------------------- raw (no autograd) interface
-    def fwd_nograd(self, x, cnoise):
-        """x [B,L], cnoise [B,1] -> [B,L]; keeps what vjp() needs until the next call."""
+    supports_lanes = True
+
+    def lane_engine(self, lane):
+        """Engine state number `lane` (saved activations + scratch of its own over the shared packed weights): a caller that
+        pipelines independent clips on its own streams (BlindSampler) passes lane=k to fwd_nograd / vjp, which then run
+        entirely on the CALLER's current stream with that state instead of forking streams themselves."""
+        eng = self.engine()
+        if getattr(self, "_lane_engines", None) is None or self._lane_engines[0] is not eng:
+            self._lane_engines = [eng]
+        while len(self._lane_engines) <= lane:
+            self._lane_engines.append(eng.clone_state())
+        return self._lane_engines[lane]
+
+    def fwd_nograd(self, x, cnoise, lane=None):
+        """x [B,L], cnoise [B,1] -> [B,L]; keeps what vjp() needs until the next call (of the same lane)."""
         assert x.device == self.device, f"input on {x.device}, network on {self.device}"
         with torch.cuda.device(self.device):       # every launch below goes to THIS device's current stream
-            return self._fwd_nograd(x, cnoise)
+            return self._fwd_nograd(x, cnoise, lane)
 
-    def _fwd_nograd(self, x, cnoise):
+    def _fwd_nograd(self, x, cnoise, lane=None):
+        if lane is not None:
+            eng = self.lane_engine(lane)
+            x = x.detach().contiguous().float()
+            assert x.shape[-1] == self.CQTransform.Ls
+            film = eng.embed(cnoise.detach().reshape(-1, 1).contiguous().float())
+            return self.CQTransform.bwd_planar(eng.forward(self.CQTransform.fwd_planar(x), film))
         eng = self.engine()
         x = x.detach().contiguous().float()
         assert x.shape[-1] == self.CQTransform.Ls, "input length must equal exp.audio_len (the CQT is built for it)"
@@ -215,13 +234,16 @@ class Unet_CQT_oct_with_attention(nn.Module):
             outs = [torch.cat([p[j] for p in parts], 0) for j in range(len(co))]
         return self.CQTransform.bwd_planar(outs)
 
-    def vjp(self, g):
-        """Gradient of <net(x), g> w.r.t. x for the last fwd_nograd call."""
+    def vjp(self, g, lane=None):
+        """Gradient of <net(x), g> w.r.t. x for the last fwd_nograd call (of the same lane)."""
         assert g.device == self.device, f"gradient on {g.device}, network on {self.device}"
         with torch.cuda.device(self.device):
-            return self._vjp(g)
+            return self._vjp(g, lane)
 
-    def _vjp(self, g):
+    def _vjp(self, g, lane=None):
+        if lane is not None:
+            eng = self.lane_engine(lane)
+            return self.CQTransform.fwd_adjoint(eng.vjp(self.CQTransform.bwd_adjoint(g.contiguous())))
         eng = self.engine()
         gouts = self.CQTransform.bwd_adjoint(g.contiguous())
         B = g.shape[0]

@@ -94,7 +94,10 @@ class BlindSampler:
         check(lib().babe_sumsq_partial(ptr(g), g.stride(0), ptr(part), self.NBLK, B, n, stream()), "sumsq_partial")
         return part
 
-    def get_denoised_estimate(self, x, t):
+    def _lane_kw(self, lane):
+        return {"lane": lane} if (lane is not None and getattr(self.model, "supports_lanes", False)) else {}
+
+    def get_denoised_estimate(self, x, t, lane=None):
         """x [B,L] device, t host float -> hpf_DC(denoiser(x))  (:152-157); keeps the UNet context for the VJP."""
         dp = self.diff_params
         s = torch.as_tensor(t, dtype=torch.float32)
@@ -102,8 +105,9 @@ class BlindSampler:
         cskip, cout, cin = self._c
         B = x.shape[0]
         xin = lincomb(torch.empty_like(x), cin, x)
-        cn = dp.cnoise(s).reshape(1, 1).expand(B, 1).contiguous().to(x.device)
-        net = self.model.fwd_nograd(xin, cn)
+        cn = torch.full((B, 1), float(dp.cnoise(s)), device=x.device, dtype=torch.float32)   # (no host-to-device copy: a
+        # pageable H2D copy in the loop would stall the host on this stream and starve the other lanes)
+        net = self.model.fwd_nograd(xin, cn, **self._lane_kw(lane))
         xd = lincomb(torch.empty_like(x), cskip, x, cout, net)
         if self.args.tester.filter_out_cqt_DC_Nyq:
             xd = self.model.CQTransform.apply_hpf_DC(xd)
@@ -117,12 +121,13 @@ class BlindSampler:
         nit = st.filter_fit(stats, p, self.fit_cfg)
         return p, nit
 
-    def evaluate(self, x, t, y, specY, filter_params, blind):
-        """One score evaluation at noise level t. Returns (d = -t*score, x_den, filter_params)."""
+    def evaluate(self, x, t, y, specY, filter_params, blind, lane=None):
+        """One score evaluation at noise level t. Returns (d = -t*score, x_den, filter_params).
+        lane: engine state of the network to use (the caller runs this call chain on a stream of its own)."""
         st = self._stft
         cq = self.model.CQTransform
         B, L = x.shape
-        x_den = self.get_denoised_estimate(x, t)
+        x_den = self.get_denoised_estimate(x, t, lane)
         cskip, cout, cin = self._c
         if y is None:
             # unconditional (get_score :160-170): d = -t*(x_den - x)/t^2
@@ -165,7 +170,7 @@ class BlindSampler:
         if self.args.tester.filter_out_cqt_DC_Nyq:
             g_den = cq.apply_hpf_DC(g_den)                      # zero-phase real filter: self-adjoint
         g_net = lincomb(torch.empty_like(g_den), cout, g_den)
-        g_xin = self.model.vjp(g_net)
+        g_xin = self.model.vjp(g_net, **self._lane_kw(lane))
         g_x = lincomb(torch.empty_like(g_den), cskip, g_den, cin, g_xin)
         gpart = self._sumsq(g_x)
         d = torch.empty_like(x)
@@ -183,19 +188,19 @@ class BlindSampler:
         return d, x_den, filter_params
 
     # ------------------------------------------------------------------ sampling loops
-    def step(self, x, t_i, gamma_i, t_next, eps, y, specY, filter_params, blind, snoise=1.0):
+    def step(self, x, t_i, gamma_i, t_next, eps, y, specY, filter_params, blind, snoise=1.0, lane=None):
         """ONE stochastic Heun step of the reverse diffusion (:687-761 / predict :439-480): noise injection
         (move_timestep :509-516), score evaluation, 2nd-order correction unless t_next == 0 or order == 1.
         Returns (x_next, filter_params, rec) with rec = dict(x_hat, t_hat, x_den, d) of the first evaluation.
         Exposed so that a step can be teacher-forced from recorded reference state (tests/test_gpu_sampler.py)."""
         t_hat = t_i + gamma_i * t_i
         x_hat = lincomb(torch.empty_like(x), 1.0, x, float((t_hat ** 2 - t_i ** 2) ** (1 / 2)) * float(snoise), eps)
-        d, x_den, filter_params = self.evaluate(x_hat, float(t_hat), y, specY, filter_params, blind)
+        d, x_den, filter_params = self.evaluate(x_hat, float(t_hat), y, specY, filter_params, blind, lane)
         rec = dict(x_hat=x_hat, t_hat=float(t_hat), x_den=x_den, d=d, filter_params=filter_params)
         h = float(t_next - t_hat)
         if float(t_next) != 0 and self.order == 2:
             x_prime = lincomb(torch.empty_like(x), 1.0, x_hat, h, d)
-            d2, _, filter_params = self.evaluate(x_prime, float(t_next), y, specY, filter_params, blind)
+            d2, _, filter_params = self.evaluate(x_prime, float(t_next), y, specY, filter_params, blind, lane)
             x = lincomb(torch.empty_like(x), 1.0, x_hat, 0.5 * h, d, 0.5 * h, d2)
         else:
             x = lincomb(torch.empty_like(x), 1.0, x_hat, h, d)
@@ -227,6 +232,9 @@ class BlindSampler:
                 t = dp.create_schedule_from_initial_t(self.start_sigma, T)
                 x = lincomb(torch.empty_like(y), 1.0, y, float(t[0]), self._randn((B, L), device).contiguous())
             gamma = dp.get_gamma(t)
+            if self._use_lanes(B, y, rid, filter_params):
+                x, filter_params = self._sample_lanes(x, y, specY, filter_params, blind, snoise, t, gamma)
+                T = 0                                        # (loop below skipped)
             for i in range(T):
                 eps = self._randn((B, L), device).contiguous()
                 x, filter_params, rec = self.step(x, t[i], gamma[i], t[i + 1], eps, y, specY, filter_params, blind, snoise)
@@ -244,6 +252,71 @@ class BlindSampler:
             fp_out = filter_params[0] if (filter_params.shape[0] == 1) else filter_params
             return (x, fp_out, data_denoised, t, data_filters) if rid else (x, fp_out)
         return (x, data_denoised, data_score, t) if rid else (x,)
+
+    # ---- clip-level pipelining -------------------------------------------------------------------------------------------
+    # Clips are independent (per-clip semantics), so their whole evaluation chains - UNet forward, CQT, STFT, the
+    # single-workgroup filter fit, guidance, UNet VJP, Heun update - run on separate HIP streams, one engine state of the
+    # network per lane.  The kernels that cannot fill the GPU on their own (filter fit: one workgroup for 1.8 ms; the dense
+    # DFT stages; the per-clip CQT / STFT launches) then overlap the other lane's convolutions instead of serialising
+    # behind a join on the caller's stream.  Enqueue order alternates between the lanes once per score evaluation so that
+    # neither queue runs dry; the noise is drawn for the whole batch in the reference's order BEFORE the loop, so results
+    # are identical to the single-stream loop.
+    LANES = 2
+
+    def _use_lanes(self, B, y, rid, filter_params):
+        return (self.LANES > 1 and B >= 2 and y is not None and not rid and self.batch_semantics == "per_clip" and
+                getattr(self.model, "supports_lanes", False) and self.ar_mask is None and self.dc is None and
+                self.fir_taps is None and filter_params.shape[0] == B)
+
+    def _sample_lanes(self, x, y, specY, filter_params, blind, snoise, t, gamma):
+        B, L = x.shape
+        T = self.nb_steps
+        dev = x.device
+        nl = min(self.LANES, B)
+        per = -(-B // nl)
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_lane_streams", None) is None or len(self._lane_streams) < nl:
+            self._lane_streams = [torch.cuda.Stream(device=dev) for _ in range(nl)]
+        noises = [self._randn((B, L), dev).contiguous() for _ in range(T)]          # reference order: one draw per step
+        lanes = []
+        for k in range(nl):
+            b0, b1 = k * per, min(B, (k + 1) * per)
+            if b0 < b1:
+                lanes.append(dict(k=k, st=self._lane_streams[k], sl=slice(b0, b1), x=x[b0:b1], y=y[b0:b1],
+                                  specY=specY[b0:b1], fp=filter_params[b0:b1].contiguous()))
+        ready = torch.cuda.Event()
+        ready.record(main)                                     # everything the lanes read has been enqueued on `main`
+        for ln in lanes:
+            ln["st"].wait_event(ready)
+        for i in range(T):
+            t_hat = t[i] + gamma[i] * t[i]
+            h = float(t[i + 1] - t_hat)
+            heun = float(t[i + 1]) != 0 and self.order == 2
+            for ln in lanes:                                   # first evaluation of step i, lane after lane
+                with torch.cuda.stream(ln["st"]):
+                    eps = noises[i][ln["sl"]]
+                    x_hat = lincomb(torch.empty_like(ln["x"]), 1.0, ln["x"].contiguous(),
+                                    float((t_hat ** 2 - t[i] ** 2) ** (1 / 2)) * float(snoise), eps)
+                    d, _, ln["fp"] = self.evaluate(x_hat, float(t_hat), ln["y"], ln["specY"], ln["fp"], blind, ln["k"])
+                    ln["x_hat"], ln["d"] = x_hat, d
+                    if not heun:
+                        ln["x"] = lincomb(torch.empty_like(x_hat), 1.0, x_hat, h, d)
+            if heun:
+                for ln in lanes:                               # second (Heun) evaluation
+                    with torch.cuda.stream(ln["st"]):
+                        x_prime = lincomb(torch.empty_like(ln["x_hat"]), 1.0, ln["x_hat"], h, ln["d"])
+                        d2, _, ln["fp"] = self.evaluate(x_prime, float(t[i + 1]), ln["y"], ln["specY"], ln["fp"], blind, ln["k"])
+                        ln["x"] = lincomb(torch.empty_like(x_prime), 1.0, ln["x_hat"], 0.5 * h, ln["d"], 0.5 * h, d2)
+        for ln in lanes:
+            done = torch.cuda.Event()
+            done.record(ln["st"])
+            main.wait_event(done)
+            ln["x"].record_stream(main)
+            ln["fp"].record_stream(main)
+        for n_ in noises:
+            for ln in lanes:
+                n_.record_stream(ln["st"])
+        return torch.cat([ln["x"] for ln in lanes], 0), torch.cat([ln["fp"] for ln in lanes], 0)
 
     def _init_params(self, B, device):
         ic = self.args.tester.blind_bwe.initial_conditions

@@ -265,6 +265,7 @@ def main():
         last = s == a.warmup - 1 and do_prof
         if last:
             lanes_keep, net.MAX_LANES = net.MAX_LANES, 1
+            slanes_keep, sampler.LANES = sampler.LANES, 1
             torch.cuda.synchronize()
             _lib.prof_read()
             _lib.prof_enable(True)
@@ -276,6 +277,7 @@ def main():
             _lib.prof_enable(False)
             serial = _lib.prof_read()
             net.MAX_LANES = lanes_keep
+            sampler.LANES = slanes_keep
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -334,10 +336,10 @@ def main():
                 "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
                 "algorithmic_gflop_per_launch_avg": round(r["flops"] / r["launches"] / 1e9, 3),
                 "profiled_steps": n_prof,
-                "timing": "HIP events on each launch's own stream over the first %d step(s) of the timed region; batch "
-                          "items run on %d streams, so these durations include overlap with the other stream's kernels: "
-                          "overlap_factor = sum of all kernel durations / wall time of those steps"
-                          % (n_prof, max(1, min(net.MAX_LANES, nseg * C_))),
+                "timing": "HIP events on each launch's own stream over the first %d step(s) of the timed region; the clips' "
+                          "whole evaluation chains run on %d streams (BlindSampler._sample_lanes), so these durations include "
+                          "overlap with the other stream's kernels: overlap_factor = sum of all kernel durations / wall time "
+                          "of those steps" % (n_prof, max(1, min(sampler.LANES, nseg * C_))),
                 "overlap_factor": round(sum_all_ms * 1e-3 / wall_prof, 4),
                 "conv_time_share_of_kernel_time": round(sum_conv_ms / sum_all_ms, 4),
                 "conv_dispatch_counts_timed_region": {k: counts[k] for k in CONV_SLOTS + ["dft_stage"]},

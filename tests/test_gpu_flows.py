@@ -29,12 +29,16 @@ class ResidualNet:
         self.inner, self.a, self.sd = inner, a, sigma_data
         self.CQTransform = inner.CQTransform
 
-    def fwd_nograd(self, x, cn):
-        self.k = float(torch.exp(4 * cn[0, 0])) / self.sd
-        return self.a * self.inner.fwd_nograd(x, cn) + self.k * x
+    supports_lanes = True
 
-    def vjp(self, g):
-        return self.a * self.inner.vjp(g) + self.k * g
+    def fwd_nograd(self, x, cn, lane=None):
+        self.k = float(torch.exp(4 * cn[0, 0])) / self.sd          # (one sigma per call; same for every lane of a step)
+        kw = {} if lane is None else {"lane": lane}
+        return self.a * self.inner.fwd_nograd(x, cn, **kw) + self.k * x
+
+    def vjp(self, g, lane=None):
+        kw = {} if lane is None else {"lane": lane}
+        return self.a * self.inner.vjp(g, **kw) + self.k * g
 
 
 def synth_recording(L, fs, seed):

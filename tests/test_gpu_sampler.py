@@ -54,12 +54,16 @@ class ResidualNet:
         self.inner, self.a, self.sd = inner, a, sigma_data
         self.CQTransform = inner.CQTransform
 
-    def fwd_nograd(self, x, cn):
-        self.k = float(torch.exp(4 * cn[0, 0])) / self.sd
-        return self.a * self.inner.fwd_nograd(x, cn) + self.k * x
+    supports_lanes = True
 
-    def vjp(self, g):
-        return self.a * self.inner.vjp(g) + self.k * g
+    def fwd_nograd(self, x, cn, lane=None):
+        self.k = float(torch.exp(4 * cn[0, 0])) / self.sd          # (one sigma per call; same for every lane of a step)
+        kw = {} if lane is None else {"lane": lane}
+        return self.a * self.inner.fwd_nograd(x, cn, **kw) + self.k * x
+
+    def vjp(self, g, lane=None):
+        kw = {} if lane is None else {"lane": lane}
+        return self.a * self.inner.vjp(g, **kw) + self.k * g
 
 
 def params_close(p, q):
@@ -425,3 +429,31 @@ def test_sub_batching_equals_one_batch_and_bf16_sampler_tolerance():
     print(f"bf16 sampler: output RMS err {e:.2e} (fp32 bar 1e-3), filters {fpb.cpu().tolist()} vs {s['filter_params'].tolist()}")
     assert e < 5e-3
     assert torch.allclose(fpb.cpu()[0], s["filter_params"][0], rtol=5e-2) and torch.allclose(fpb.cpu()[1], s["filter_params"][1], atol=2.0)
+
+
+def test_clip_lanes_equal_single_stream_loop():
+    """per-clip batches run their clips' whole evaluation chains on separate HIP streams (BlindSampler._sample_lanes, one
+    network engine state per lane); with the same noise the result is bit-identical to the single-stream loop and to
+    single-clip runs, for an even and an odd batch."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    g, args, net = small_net(T=3, start_sigma=0.05)
+    L = 92092
+    gen = torch.Generator().manual_seed(77)
+    y = 0.1 * torch.randn(3, L, generator=gen)
+    noises = [torch.randn(3, L, generator=gen) for _ in range(4)]
+    for B in (2, 3):
+        outs = []
+        for lanes in (2, 1):
+            smp = BlindSampler(net, EDM(args), args, batch_semantics="per_clip")
+            smp.LANES = lanes
+            it = iter([n[:B] for n in noises])
+            smp._randn = lambda shape, device: next(it).to(device)
+            outs.append(smp.predict_blind_bwe(y[:B].cuda()))
+            torch.cuda.synchronize()
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), B
+    smp = BlindSampler(net, EDM(args), args)
+    it = iter([n[2:3] for n in noises])
+    smp._randn = lambda shape, device: next(it).to(device)
+    x1, fp1 = smp.predict_blind_bwe(y[2:3].cuda())
+    assert torch.equal(outs[0][0][2:3], x1) and torch.equal(outs[0][1][2], fp1)
