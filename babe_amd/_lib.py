@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libbabe_hip.so")
+_LIB_PATH = os.environ.get("BABE_HIP_LIB") or os.path.join(_HERE, "libbabe_hip.so")
 _lib = None
 
 

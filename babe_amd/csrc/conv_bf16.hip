@@ -338,6 +338,9 @@ void launch(const babe_conv_args& a, ConvGeomB g, const unsigned short* wq, hipS
 
 }  // namespace
 
+int babe_conv2d_bf16p_supported(const babe_conv_args& a);       // conv_bf16p.hip
+int babe_conv2d_bf16p_launch(const babe_conv_args& a, const unsigned short* wq, hipStream_t s);
+
 extern "C" long babe_conv_packed_size_bf16(int Cout, int Cin, int KH, int KW, int transpose_flip, int splits) {
     const int co = transpose_flip ? Cin : Cout;
     const int ci = transpose_flip ? Cout : Cin;
@@ -383,6 +386,12 @@ extern "C" int babe_conv2d_bf16(const babe_conv_args* ap, const void* w_bf16, in
     hipStream_t s = (hipStream_t)stream;
     const unsigned short* wq = (const unsigned short*)w_bf16;
     const double flops = babe_conv_flops(a);
+    if (splits == 1 && babe_conv2d_bf16p_supported(a)) {       // round-2 pipelined kernel, same arguments and weights
+        BabeProfScope prof(BABE_SLOT_CONV_BF16P, babe_conv_bytes(a), flops, flops, stream);
+        babe_conv2d_bf16p_launch(a, wq, s);
+        BABE_LAUNCH_CHECK();
+        return BABE_OK;
+    }
     BabeProfScope prof(BABE_SLOT_CONV_BF16, babe_conv_bytes(a), flops, flops * (splits == 2 ? 3 : 1), stream);
 #define BC(NTv, WPv)                                                              \
     if (a.KW == 3) {                                                              \

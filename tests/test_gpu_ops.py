@@ -338,3 +338,47 @@ def test_unet_body_fwd_and_vjp_small():
     gC = eng.vjp([go.cuda() for go in gouts])
     for a, r in zip(gC, grefs):
         assert rel(a, r) < 1e-4
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,Fq,T,dil", [
+    (2, 64, 0, 64, 64, 1024, 2),       # 64-channel tile, two time tiles per row
+    (1, 96, 96, 96, 40, 36, 4),        # two sources (split % 32 == 0), 96 channels on the 128-channel tile, T < tile
+    (1, 128, 0, 256, 33, 128, 16),     # two channel blocks, ragged F, taps skipped at the borders
+    (2, 72, 0, 128, 9, 272, 1),        # Cin % 32 != 0 (zero channel groups), T not a power of two
+    (1, 32, 32, 64, 70, 16, 8),        # shortest rows: 32 rows per tile, 64 halo lanes
+    (1, 256, 0, 128, 24, 2048, 1),     # long rows, four time tiles
+])
+def test_conv2d_bf16_pipelined_vs_rounded_operands(ops, B, C1, C2, Cout, Fq, T, dil):
+    """The pipelined bf16 (5,3) kernel (csrc/conv_bf16p.hip) computes EXACTLY conv(bf16(x*in_scale), bf16(w)) with fp32
+    accumulation: against float64 on the rounded operands the error is accumulation rounding only (1e-6), which pins
+    staging, swizzle, halo, zero padding and the two-source split independently of the bf16 quantisation (1e-2)."""
+    from babe_amd._lib import dispatch_counts
+    g = torch.Generator().manual_seed(C1 + Cout + T)
+    Cin = C1 + C2
+    x = torch.randn(B, Cin, Fq, T, generator=g)
+    w = torch.randn(Cout, Cin, 5, 3, generator=g) / math.sqrt(Cin * 15)
+    res = torch.randn(B, Cout, Fq, T, generator=g)
+    osc = torch.randn(B, Cout, generator=g)
+    rb = lambda t: t.to(torch.bfloat16).double()
+    ref = 0.7 * UN.conv_same(rb(x), rb(w), dil) * osc[:, :, None, None].double() + 0.3 * res.double()
+    pc = ops.PackedConv(w.cuda(), "bf16")
+    xc = x.cuda()
+    x1, x2 = (xc[:, :C1].contiguous(), xc[:, C1:].contiguous()) if C2 else (xc, None)
+    big = torch.zeros(B, Cout, 2 * Fq, T, device="cuda")
+    o = big[:, :, Fq:, :]
+    o.copy_(res.cuda())
+    c0 = dispatch_counts()["conv_bf16p"]
+    ops.conv2d(x1, pc, o, dil=dil, x2=x2, res=o, oscale=osc.cuda(), alpha=0.7, rbeta=0.3)
+    assert dispatch_counts()["conv_bf16p"] == c0 + 1
+    assert rel(o, ref) < 3e-6
+    assert float(big[:, :, :Fq, :].abs().max()) == 0.0
+    # input-VJP with the folded per-channel scale: bf16(gy * isc) against bf16(w), transposed + flipped
+    gy = torch.randn(B, Cout, Fq, T, generator=g)
+    isc = torch.randn(B, Cout, generator=g)
+    gs = (gy * isc[:, :, None, None])
+    wt = w.flip(2, 3).transpose(0, 1)
+    gref = UN.conv_same(rb(gs), rb(wt), dil)
+    gx = torch.empty(B, Cin, Fq, T, device="cuda")
+    ops.conv2d(gy.cuda(), pc, gx, dil=dil, transpose=True, in_scale=isc.cuda())
+    assert dispatch_counts()["conv_bf16p"] == c0 + 2
+    assert rel(gx, gref) < 3e-6
