@@ -1,52 +1,58 @@
 // bf16-MFMA (5,3) dilated conv, PIPELINED (round 2): the kernel behind precision='bf16' for the configurations that the
-// reference runs under bf16 autocast (BASELINE.json configs[2]-[4]).  Same contract, packed weights and epilogue as
+// reference runs under bf16 autocast (BASELINE.json configs[2]-[4]).  Same contract, packed weights and arithmetic as
 // conv_bf16.hip (direct convolution, v_mfma_f32_32x32x16_bf16, fp32 accumulate, activations fp32 in HBM and rounded to
 // bf16 on their way into LDS); what changes is how operands travel, because at bf16 rates the round-1 kernel was bound
-// by its staging code (one dword load per thread, position and channel):
+// by its staging code (one dword load per thread, position and channel) and by LDS reads (three shifted B operands
+// per position tile, one per time tap):
 //
-//   * 512 threads, one workgroup per CU, tile = 128 (or 64) output channels x 512 positions, K-slab = 32 input channels
-//     of one frequency tap: 48 (24) MFMAs per wave between barriers, 0.75 (1.0) ds_read_b128 per MFMA.
-//   * activations through raw BUFFER loads, 16 bytes = 4 time positions of one channel per lane; zero padding (rows,
-//     columns, channels beyond Cin) is the hardware range check.  A thread owns 8 channels x 4 positions, i.e. four
-//     complete 16-byte MFMA operand units; the two halo columns of a row are eight dword loads on a few lanes, predicated
-//     by the same range check (idle lanes load nothing and write a dummy LDS slot: no branches in the slab body).
-//   * LDS image [channel group][unit] with unit u stored at u ^ ((u >> 4) & 3): a thread's four units are 64 bytes apart
-//     from its neighbour's, which would be a 4-way bank conflict on the ds_write_b128; the XOR makes the writes of 16
-//     consecutive lanes hit 16 distinct 16-byte bank groups and keeps the reads (32 consecutive units) conflict-free.
+//   * POSITION-INTERLEAVED tiles.  A wave owns 128 consecutive positions as FOUR 32-column MFMA tiles, tile q holding
+//     positions 4l + q (l = lane & 31).  The B operand of tile q for time tap kw is then the unit set S(q + kw) =
+//     {unit 4l + q + kw}: twelve (tile, tap) uses share SIX operand reads S(0..5) - half the LDS B traffic of
+//     contiguous tiles - and the four tiles' accumulators of one output channel are four consecutive time steps in ONE
+//     lane: the epilogue stores (and reads the residual as) 16-byte vectors.
+//   * LDS image [channel group][row][plane u & 3][u >> 2] of 16-byte units (unit u = 8 channels of time step
+//     t0 - 1 + u): every S(m) is a run of consecutive units (conflict-free ds_read_b128) and a staging thread's four
+//     units go to four planes at one index (conflict-free ds_write_b128, no swizzle).
+//   * activations through raw BUFFER loads, 16 bytes = 4 time steps of one channel per lane; zero padding (rows,
+//     columns, channels beyond Cin) is the hardware range check.  A thread owns 8 channels x 4 time steps = four
+//     complete units; the two halo columns of a row are eight dword loads on a few lanes, predicated by the same range
+//     check (idle lanes load nothing and write a dummy LDS slot: no branches in the slab body).
 //   * weights by LDS-DMA through a buffer descriptor (per-thread offsets are loop constants, the slab a scalar offset).
 //   * two LDS buffers; slab j+1 is converted and written, and the raw loads of slab j+2 are issued, in the shadow of
 //     the MFMAs of slab j.
+//   * two shapes of one template <G = channel groups per slab>: G = 4 -> 512 threads, 128 co x 512 positions, 32-channel
+//     slabs, one workgroup per CU; G = 2 -> 256 threads, 64 co x 512 positions, 16-channel slabs, two workgroups per CU
+//     (the 64-channel layers are HBM-bound: a second workgroup covers the first one's prologue and epilogue).
 //
 // Requirements beyond conv_bf16.hip's: KW == 3, T % 4 == 0, Cin % 8 == 0, cin_split % 32 == 0, every source view below
-// 2 GiB per batch item, Cout > 32.  Anything else (and bf16x3) runs on the round-1 kernel.
+// 2 GiB per batch item, Cout > 32, 16-byte aligned rows of out / res.  Anything else (and bf16x3) runs on the round-1 kernel.
 #include "conv_common.h"
 #include "prof.h"
 #include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 struct Bf16pGeom {
-    int GP, CoutP, pt_log2, pr_log2, tiles_t;
+    int GP, CoutP, pt_log2, pr_log2, tiles_t, tiles_f, ncb, total;
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr unsigned OOB = 0x80000000u;      // beyond every descriptor's num_records: the load returns 0, touches nothing
 
-__device__ __forceinline__ int swz(int u) { return u ^ ((u >> 4) & 3); }
+#ifndef ABL
+#define ABL 0
+#endif
 
-template <int NT, int NP, int WR, int WC, bool HAS_ISC>
-__global__ __launch_bounds__(512, 1) void conv_bf16p_kernel(babe_conv_args a, Bf16pGeom g,
-                                                            const unsigned short* __restrict__ wq) {
+template <int G, bool HAS_ISC>
+__global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(babe_conv_args a, Bf16pGeom g,
+                                                                               const unsigned short* __restrict__ wq) {
 #if __HIP_DEVICE_COMPILE__      // buffer-descriptor builtins exist in the device pass only
-    static_assert(WR * WC == 8, "eight waves");
-    constexpr int NTH = 512, KC = 32, G = 4;
+    constexpr int NT = 2, NP = 4, WC = 4, WR = G / 2;
+    constexpr int NTH = 128 * G, KC = 8 * G, NGP = G / 2;
     constexpr int BN = WR * NT * 32;
-    constexpr int NPOS = WC * NP * 32;
-    static_assert(NPOS == 512, "one staging quad per thread and channel group");
-    constexpr int XCHP = NPOS + NPOS / 8;             // units per channel group: PR rows of PT+2, PR <= NPOS/16
+    constexpr int XCHP = 640;                         // units per channel group: PR rows of PT + 4, PR <= 32
     constexpr int XSZ = G * XCHP;
     constexpr int NWU = 3 * G * BN;                   // weight units per slab
     constexpr int WJ = (NWU + NTH - 1) / NTH;
@@ -56,13 +62,23 @@ __global__ __launch_bounds__(512, 1) void conv_bf16p_kernel(babe_conv_args a, Bf
 
     const int PT = 1 << g.pt_log2;
     const int PR = 1 << g.pr_log2;
-    const int XROW = PT + 2;
-    const int tile_t = blockIdx.x % g.tiles_t;
-    const int tile_f = blockIdx.x / g.tiles_t;
+    const int PI = (PT >> 2) + 1;                     // units per plane and row
+    const int RU = 4 * PI;                            // units per row
+    // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id; tiles that read the same input rows
+    // (the two channel blocks of a tile, then the frequency-neighbours of a time column) are given to ONE XCD as a
+    // contiguous chunk of the list [batch][time tile][row tile][channel block], so the five-tap re-reads hit that XCD's L2.
+    const int per_xcd = (g.total + 7) >> 3;
+    int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || lin >= g.total) return;
+    const int cb = lin % g.ncb;
+    lin /= g.ncb;
+    const int tile_f = lin % g.tiles_f;
+    lin /= g.tiles_f;
+    const int tile_t = lin % g.tiles_t;
+    const int b = lin / g.tiles_t;
     const int t0 = tile_t << g.pt_log2;
     const int f0 = tile_f << g.pr_log2;
-    const int co0 = blockIdx.y * BN;
-    const int b = blockIdx.z;
+    const int co0 = cb * BN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,7 +102,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16p_kernel(babe_conv_args a, Bf
     const __amdgpu_buffer_rsrc_t rsw =
         __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, a.KH * 3 * g.GP * g.CoutP * 16, 0x00020000);
 
-    // ---- staging constants.  Channel group = tid / 128 (wave-uniform), inside it 128 quads of 4 time positions.
+    // ---- staging constants.  Channel group = tid / 128 (wave-uniform), inside it 128 quads of 4 time steps.
     const int gw = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int lt = tid & 127;
     const int i4 = lt & ((PT >> 2) - 1);
@@ -94,14 +110,16 @@ __global__ __launch_bounds__(512, 1) void conv_bf16p_kernel(babe_conv_args a, Bf
     const int st = t0 + 4 * i4;
     const int xspat4 = ((f0 + srow) * a.T + st) * 4;
     const unsigned xcolbad = st < a.T ? 0u : OOB;
-    const int u0 = srow * XROW + 1 + 4 * i4;
-    // halo: lanes lt < 2*PR of every group own (row, side) = (lt >> 1, lt & 1)
+    // units 4*i4 + 1 .. 4*i4 + 4 of the row: planes 1, 2, 3 at index i4 and plane 0 at index i4 + 1
+    const int xslot = gw * XCHP + srow * RU + i4;
+    // halo: lanes lt < 2*PR of every group own (row, side) = (lt >> 1, lt & 1): unit 0 (plane 0, index 0) or unit PT + 1
+    // (plane 1, index PT / 4)
     const bool hl = lt < 2 * PR;
     const int hrow = lt >> 1;
     const int ht = (lt & 1) ? t0 + PT : t0 - 1;
     const int hspat4 = ((f0 + hrow) * a.T + ht) * 4;
     const unsigned hbad = (hl && ht >= 0 && ht < a.T) ? 0u : OOB;
-    const int hslot = hl ? gw * XCHP + swz(hrow * XROW + ((lt & 1) ? PT + 1 : 0)) : XSZ + WJ * NTH;
+    const int hslot = hl ? gw * XCHP + hrow * RU + ((lt & 1) ? PI + (PT >> 2) : 0) : XSZ + WJ * NTH;
     int wvo[WJ];
 #pragma unroll
     for (int jj = 0; jj < WJ; ++jj) {
@@ -125,11 +143,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16p_kernel(babe_conv_args a, Bf
     f32x4 xv[8];
     float xh[8], xsc[8];
 
-#ifndef ABL
-#define ABL 0
-#endif
     auto issue_act = [&](int kh, int ci0) {
-        if (ABL == 1) return;
+        if (ABL & 1) return;
         const int foff = (kh - khc) * a.dil;
         const bool s2 = ci0 >= split;
         const int nch = s2 ? a.Cin - split : split;
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16p_kernel(babe_conv_args a, Bf
             for (int j = 0; j < 8; ++j) {
                 int ci = ci0 + 8 * gw + j;
                 ci = ci < a.Cin ? ci : a.Cin - 1;
-                xsc[j] = a.in_scale[(long)b * a.Cin + ci];                 // scalar loads (wave-uniform address)
+                xsc[j] = a.in_scale[(long)b * a.Cin + ci];                 // wave-uniform address
             }
         }
     };
@@ -165,42 +180,46 @@ __global__ __launch_bounds__(512, 1) void conv_bf16p_kernel(babe_conv_args a, Bf
         return o;
     };
     auto store_main = [&](bf16x8* buf, int k0, int k1) {
+        if (ABL & 8) return;
 #pragma unroll
         for (int k = k0; k < k1; ++k) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = xv[j][k];
-            buf[gw * XCHP + swz(u0 + k)] = pack8(v);
+            buf[xslot + (k == 3 ? 1 : (k + 1) * PI)] = pack8(v);           // unit 4*i4 + 1 + k
         }
     };
-    auto store_halo = [&](bf16x8* buf) { buf[hslot] = pack8(xh); };
+    auto store_halo = [&](bf16x8* buf) { if (!(ABL & 8)) buf[hslot] = pack8(xh); };
     auto dma_w = [&](int kh, int ci0, bf16x8* buf) {
+        if (ABL & 32) return;
         const int so = ((kh * 3) * g.GP + (ci0 >> 3)) * g.CoutP * 16;      // bytes, scalar
 #pragma unroll
         for (int jj = 0; jj < WJ; ++jj)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(buf + XSZ + jj * NTH + wave * 64), 16, wvo[jj], so, 0, 0);
     };
+    // Slab order: channel slab OUTER, frequency tap INNER.  The rows a tile reads for tap kh+1 are the rows its
+    // frequency-neighbours read for tap kh: with the taps innermost those re-reads fall within a few slabs of each other,
+    // while the live footprint (one channel slab of the XCD's rows) still fits the 4 MB L2.
     auto advance = [&](int& kh, int& ci0) {             // next slab, clamped at the last one
-        int nc = ci0 + KC, nk = kh;
-        if (nc >= CinP) {
-            nc = 0;
-            ++nk;
+        int nk = kh + 1, nc = ci0;
+        if (nk > kh_hi) {
+            nk = kh_lo;
+            nc += KC;
         }
-        if (nk <= kh_hi) {
+        if (nc < CinP) {
             kh = nk;
             ci0 = nc;
         }
     };
 
-    // operand addresses (units).  B: position p of tap kw is unit row*XROW + tt + kw of channel group 2*gp + h.
-    int boff[NP][3];
+    // ---- operand addresses (units).  This lane's four tiles hold positions p0 + q, p0 = wc*128 + 4*l31; S(m) is unit
+    // tt0 + m of its row: plane m & 3, index tt0 / 4 + (m >> 2), of channel group 2*gp + h.
+    const int p0 = wc * 128 + 4 * l31;
+    const int prow = p0 >> g.pt_log2;
+    const int tt0 = p0 & (PT - 1);
+    int boff[6];
 #pragma unroll
-    for (int np = 0; np < NP; ++np) {
-        const int p = (wc * NP + np) * 32 + l31;
-        const int u = (p >> g.pt_log2) * XROW + (p & (PT - 1));
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) boff[np][kw] = h * XCHP + swz(u + kw);
-    }
+    for (int m = 0; m < 6; ++m) boff[m] = h * XCHP + prow * RU + (m & 3) * PI + (tt0 >> 2) + (m >> 2);
     const int aoff = XSZ + h * BN + wr * (NT * 32) + l31;
 
     // ---- prologue: slab 0 into buffer 0, raw loads of slab 1 in flight
@@ -214,74 +233,88 @@ __global__ __launch_bounds__(512, 1) void conv_bf16p_kernel(babe_conv_args a, Bf
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the weight DMA of slab 0 (older than the 16 raw loads of slab 1)
     __syncthreads();
 
-    // MFMA schedule of a slab: six K-steps (channel-group pair gp = s / 3, time tap kw = s % 3), each in two halves of
-    // NP/2 position tiles.  A operands are double-buffered per step, B operands per half-step: the reads of the next
-    // half-step are issued before the MFMAs of the current one (NT*NP/2 MFMAs >= 128 cycles cover the LDS latency).
-    constexpr int NH = NP / 2;
-    bf16x8 av[2][NT], bv[2][NH];
+    // MFMA schedule of a slab: NGP channel-group pairs x 3 time taps; tap kw of pair gp multiplies A(gp, kw) with
+    // S(gp, kw .. kw + 3).  S(m + 4) and A(kw + 1) are read while tap kw is multiplied; the first operands of the next pair
+    // are read during the last tap of the current one.
+    bf16x8 av[2][NT], sv[2][6];
     int cur = 0;
     for (int j = 0; j < nslab; ++j) {
         const bf16x8* Xs = smem + cur * BUF;
         bf16x8* Xw = smem + (cur ^ 1) * BUF;
-#define READ_A(c, s) \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) av[c][nt] = Xs[aoff + (((s) % 3) * G + 2 * ((s) / 3)) * BN + nt * 32];
-#define READ_B(d, s, hf) \
-    _Pragma("unroll") for (int q = 0; q < NH; ++q) bv[d][q] = Xs[boff[(hf) * NH + q][(s) % 3] + 2 * ((s) / 3) * XCHP];
-#define MFMA_HALF(c, d, hf)                                                                                  \
-    if (ABL != 2) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int q = 0; q < NH; ++q)         \
-        acc[nt][(hf) * NH + q] =                                                                             \
-            __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c][nt], bv[d][q], acc[nt][(hf) * NH + q], 0, 0, 0);  \
+#define READ_A(c, gp, kw) if (!(ABL & 4) || j == 0) \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) av[c][nt] = Xs[aoff + ((kw) * G + 2 * (gp)) * BN + nt * 32];
+#define READ_S(gp, m) if (!(ABL & 4) || j == 0) sv[(gp) & 1][m] = Xs[boff[m] + 2 * (gp) * XCHP];
+#define MFMA_TAP(c, gp, kw)                                                                                   \
+    if (!(ABL & 2)) _Pragma("unroll") for (int q = 0; q < NP; ++q) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) \
+        acc[nt][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c][nt], sv[(gp) & 1][q + (kw)], acc[nt][q], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);
-        READ_A(0, 0)
-        READ_B(0, 0, 0)
+        READ_S(0, 0) READ_S(0, 1) READ_A(0, 0, 0) READ_S(0, 2) READ_S(0, 3)
         dma_w(kA, cA, Xw);                         // weights of slab j+1: issued BEFORE this slab's raw loads (see the wait below)
-        // step 0
-        READ_B(1, 0, 1) READ_A(1, 1)
-        store_main(Xw, 0, 1);
-        MFMA_HALF(0, 0, 0)
-        READ_B(0, 1, 0)
-        store_main(Xw, 1, 2);
-        MFMA_HALF(0, 1, 1)
-        // step 1
-        READ_B(1, 1, 1) READ_A(0, 2)
-        store_main(Xw, 2, 3);
-        MFMA_HALF(1, 0, 0)
-        READ_B(0, 2, 0)
-        store_main(Xw, 3, 4);
+        // pair 0, tap 0
+        READ_S(0, 4) READ_A(1, 0, 1)
+        store_main(Xw, 0, 2);
+        MFMA_TAP(0, 0, 0)
+        // pair 0, tap 1
+        READ_S(0, 5) READ_A(0, 0, 2)
+        store_main(Xw, 2, 4);
         store_halo(Xw);
-        MFMA_HALF(1, 1, 1)
-        // step 2: the staging registers are free again -> raw loads of slab j+2
-        READ_B(1, 2, 1) READ_A(1, 3)
+        MFMA_TAP(1, 0, 1)
+        // pair 0, tap 2: the staging registers are free again -> raw loads of slab j+2
+        if (NGP == 2) { READ_S(1, 0) READ_S(1, 1) READ_A(1, 1, 0) }
         advance(kA, cA);
         issue_act(kA, cA);
-        MFMA_HALF(0, 0, 0)
-        READ_B(0, 3, 0)
-        MFMA_HALF(0, 1, 1)
-        // step 3
-        READ_B(1, 3, 1) READ_A(0, 4)
-        MFMA_HALF(1, 0, 0)
-        READ_B(0, 4, 0)
-        MFMA_HALF(1, 1, 1)
-        // step 4
-        READ_B(1, 4, 1) READ_A(1, 5)
-        MFMA_HALF(0, 0, 0)
-        READ_B(0, 5, 0)
-        MFMA_HALF(0, 1, 1)
-        // step 5
-        READ_B(1, 5, 1)
-        MFMA_HALF(1, 0, 0)
-        MFMA_HALF(1, 1, 1)
+        MFMA_TAP(0, 0, 2)
+        if (NGP == 2) {
+            READ_S(1, 2) READ_S(1, 3)
+            READ_S(1, 4) READ_A(0, 1, 1)
+            MFMA_TAP(1, 1, 0)
+            READ_S(1, 5) READ_A(1, 1, 2)
+            MFMA_TAP(0, 1, 1)
+            MFMA_TAP(1, 1, 2)
+        }
         // Vector-memory operations retire in order: WJ weight DMAs, then this slab's 16 raw loads.  At most 16
         // outstanding = this wave's share of the weight slab is in LDS; the barrier then publishes it to the other waves.
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        __syncthreads();
+        if (!(ABL & 16)) __syncthreads();
         cur ^= 1;
     }
 #undef READ_A
-#undef READ_B
-#undef MFMA_HALF
+#undef READ_S
+#undef MFMA_TAP
 
-    conv_epilogue<NT, NP>(a, acc, b, co0 + wr * (NT * 32), f0, t0, g.pt_log2, wc, l31, h);
+    // ---- epilogue: out = alpha*acc*oscale[b,co] + rbeta*res; a lane's four tiles are four consecutive time steps
+    {
+        const int f = f0 + prow;
+        const int t = t0 + tt0;
+        const bool pv = f < a.F && t < a.T;
+        const long sp = pv ? (long)f * a.T + t : 0;
+        const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int co_q = co0 + wr * (NT * 32) + nt * 32 + 8 * qd + 4 * h;
+                int cc[4];
+                float os[4];
+                f32x4 rr[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cc[k] = co_q + k < a.Cout ? co_q + k : a.Cout - 1;
+                    os[k] = has_os ? a.oscale[b * a.Cout + cc[k]] : 1.f;
+                    rr[k] = has_res ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)cc[k] * a.res_cs + sp)
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * qd + k;
+                    f32x4 y = {acc[nt][0][r], acc[nt][1][r], acc[nt][2][r], acc[nt][3][r]};
+                    y = y * (a.alpha * os[k]) + a.rbeta * rr[k];
+                    if (pv && co_q + k < a.Cout)
+                        *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)(co_q + k) * a.out_cs + sp) = y;
+                }
+            }
+        }
+    }
 #endif
 }
 
@@ -291,31 +324,31 @@ inline int ilog2_ceil_b(int v) {
     return l;
 }
 
-template <int NT, int NP, int WR, int WC>
+template <int G>
 void launch_bf16p(const babe_conv_args& a, Bf16pGeom g, const unsigned short* wq, hipStream_t s) {
-    constexpr int BN = WR * NT * 32;
+    constexpr int BN = 32 * G, NTH = 128 * G;
     g.pt_log2 = ilog2_ceil_b(a.T);
     if (g.pt_log2 > 9) g.pt_log2 = 9;
     if (g.pt_log2 < 4) g.pt_log2 = 4;
     g.pr_log2 = 9 - g.pt_log2;
     const int PT = 1 << g.pt_log2, PR = 1 << g.pr_log2;
     g.tiles_t = cdiv(a.T, PT);
-    const int tiles_f = cdiv(a.F, PR);
-    dim3 grid(g.tiles_t * tiles_f, cdiv(g.CoutP, BN), a.B);
-    constexpr int WJ = (3 * 4 * BN + 511) / 512;
-    const size_t lds = 2 * (size_t)(4 * 576 + WJ * 512 + 4) * 16;
+    g.tiles_f = cdiv(a.F, PR);
+    g.ncb = cdiv(g.CoutP, BN);
+    g.total = g.tiles_t * g.tiles_f * g.ncb * a.B;
+    dim3 grid(8 * ((g.total + 7) / 8));
+    constexpr int WJ = (3 * G * BN + NTH - 1) / NTH;
+    const size_t lds = 2 * (size_t)(G * 640 + WJ * NTH + 4) * 16;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<NT, NP, WR, WC, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<NT, NP, WR, WC, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    if (a.in_scale)
-        hipLaunchKernelGGL((conv_bf16p_kernel<NT, NP, WR, WC, true>), grid, dim3(512), lds, s, a, g, wq);
-    else
-        hipLaunchKernelGGL((conv_bf16p_kernel<NT, NP, WR, WC, false>), grid, dim3(512), lds, s, a, g, wq);
+    if (a.in_scale) hipLaunchKernelGGL((conv_bf16p_kernel<G, true>), grid, dim3(NTH), lds, s, a, g, wq);
+    else hipLaunchKernelGGL((conv_bf16p_kernel<G, false>), grid, dim3(NTH), lds, s, a, g, wq);
 }
 
 }  // namespace
@@ -326,6 +359,9 @@ int babe_conv2d_bf16p_supported(const babe_conv_args& a) {
     if (ov && ov[0] == '0') return 0;
     if (a.KW != 3 || (a.T & 3) || (a.Cin & 7) || a.Cout <= 32) return 0;
     if (a.in2 && (a.cin_split % 32 != 0)) return 0;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (!al16(a.out) || (a.out_bs & 3) || (a.out_cs & 3)) return 0;                   // 16-byte epilogue vectors
+    if (a.res && (!al16(a.res) || (a.res_bs & 3) || (a.res_cs & 3))) return 0;
     const long lim = 0x7fffffffL / 4;
     const int split = a.in2 ? a.cin_split : a.Cin;
     if ((long)split * a.in_cs >= lim) return 0;
@@ -338,7 +374,7 @@ int babe_conv2d_bf16p_launch(const babe_conv_args& a, const unsigned short* wq, 
     Bf16pGeom g;
     g.GP = (a.Cin + 15) / 16 * 2;
     g.CoutP = (a.Cout + 31) / 32 * 32;
-    if (g.CoutP == 64) launch_bf16p<2, 2, 1, 8>(a, g, wq, s);      //  64 co x 512 positions
-    else launch_bf16p<2, 4, 2, 4>(a, g, wq, s);                    // 128 co x 512 positions
+    if (g.CoutP == 64) launch_bf16p<2>(a, g, wq, s);      //  64 co x 512 positions, 4 waves, two workgroups per CU
+    else launch_bf16p<4>(a, g, wq, s);                    // 128 co x 512 positions, 8 waves
     return 0;
 }

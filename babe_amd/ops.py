@@ -19,6 +19,7 @@ def _view(t):
 
 
 PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
+BF16_HBM_F32 = os.environ.get("BABE_BF16_HBM_F32", "1") != "0"
 # debug switch for the (5,3) fp32 convs: 0 = direct kernel only, 2 = Winograd F(2,3) only, 4 (default) = F(4,3) where the
 # problem qualifies, F(2,3) otherwise
 _W = os.environ.get("BABE_CONV_WINO", "4")
@@ -36,6 +37,10 @@ class PackedConv:
         self.precision = precision
         self.nt = nt
         self.splits = PRECISIONS[precision]
+        # HBM-bound shapes gain nothing from bf16 MFMA: (1,1) kernels and convs with <= 4 channels on one side run on the
+        # fp32 kernels (all-DMA (1,1) kernel, few-channel kernels) whatever the requested precision - exact AND faster.
+        if self.splits and BF16_HBM_F32 and (w.shape[2] * w.shape[3] == 1 or min(w.shape[0], w.shape[1]) <= 4):
+            self.splits = 0
         if self.splits:
             self._init_bf16(w)
             return
