@@ -237,6 +237,9 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
     // S(gp, kw .. kw + 3).  S(m + 4) and A(kw + 1) are read while tap kw is multiplied; the first operands of the next pair
     // are read during the last tap of the current one.
     bf16x8 av[2][NT], sv[2][6];
+    // 96 output channels on the 128-channel tile: the upper row-tile of the wr = 1 waves is all padding - those waves skip
+    // its MFMAs (wave-uniform; every SIMD hosts one wr = 0 and one wr = 1 wave, so the matrix pipes stay balanced)
+    const bool both = co0 + wr * (NT * 32) + 32 < a.Cout;
     int cur = 0;
     for (int j = 0; j < nslab; ++j) {
         const bf16x8* Xs = smem + cur * BUF;
@@ -245,8 +248,12 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) av[c][nt] = Xs[aoff + ((kw) * G + 2 * (gp)) * BN + nt * 32];
 #define READ_S(gp, m) if (!(ABL & 4) || j == 0) sv[(gp) & 1][m] = Xs[boff[m] + 2 * (gp) * XCHP];
 #define MFMA_TAP(c, gp, kw)                                                                                   \
-    if (!(ABL & 2)) _Pragma("unroll") for (int q = 0; q < NP; ++q) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) \
-        acc[nt][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c][nt], sv[(gp) & 1][q + (kw)], acc[nt][q], 0, 0, 0); \
+    if (!(ABL & 2)) {                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < NP; ++q)                                                        \
+            acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c][0], sv[(gp) & 1][q + (kw)], acc[0][q], 0, 0, 0); \
+        if (both) _Pragma("unroll") for (int q = 0; q < NP; ++q)                                              \
+            acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c][1], sv[(gp) & 1][q + (kw)], acc[1][q], 0, 0, 0); \
+    }                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);
         READ_S(0, 0) READ_S(0, 1) READ_A(0, 0, 0) READ_S(0, 2) READ_S(0, 3)
         dma_w(kA, cA, Xw);                         // weights of slab j+1: issued BEFORE this slab's raw loads (see the wait below)
