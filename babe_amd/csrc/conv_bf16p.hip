@@ -24,7 +24,7 @@
 //     slabs, one workgroup per CU; G = 2 -> 256 threads, 64 co x 512 positions, 16-channel slabs, two workgroups per CU
 //     (the 64-channel layers are HBM-bound: a second workgroup covers the first one's prologue and epilogue).
 //
-// Requirements beyond conv_bf16.hip's: KW == 3, T % 4 == 0, Cin % 8 == 0, cin_split % 32 == 0, every source view below
+// Kernels: (5,3) and (1,1) (one tap, no halo).  Requirements beyond conv_bf16.hip's: T % 4 == 0, Cin % 8 == 0, cin_split % 32 == 0, every source view below
 // 2 GiB per batch item, Cout > 32, 16-byte aligned rows of out / res.  Anything else (and bf16x3) runs on the round-1 kernel.
 #include "conv_common.h"
 #include "prof.h"
@@ -45,7 +45,7 @@ constexpr unsigned OOB = 0x80000000u;      // beyond every descriptor's num_reco
 #define ABL 0
 #endif
 
-template <int G, bool HAS_ISC>
+template <int G, int KW, bool HAS_ISC>
 __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(babe_conv_args a, Bf16pGeom g,
                                                                                const unsigned short* __restrict__ wq) {
 #if __HIP_DEVICE_COMPILE__      // buffer-descriptor builtins exist in the device pass only
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
     constexpr int BN = WR * NT * 32;
     constexpr int XCHP = 640;                         // units per channel group: PR rows of PT + 4, PR <= 32
     constexpr int XSZ = G * XCHP;
-    constexpr int NWU = 3 * G * BN;                   // weight units per slab
+    constexpr int NWU = KW * G * BN;                  // weight units per slab
     constexpr int WJ = (NWU + NTH - 1) / NTH;
     constexpr int BUF = XSZ + WJ * NTH + 4;           // + the dummy slot idle halo lanes write
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
     const int cs1 = (int)a.in_cs, cs2 = a.in2 ? (int)a.in2_cs : (int)a.in_cs;
     const int nb1 = split * cs1 * 4, nb2 = (a.Cin - split) * cs2 * 4;
     const __amdgpu_buffer_rsrc_t rsw =
-        __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, a.KH * 3 * g.GP * g.CoutP * 16, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, a.KH * KW * g.GP * g.CoutP * 16, 0x00020000);
 
     // ---- staging constants.  Channel group = tid / 128 (wave-uniform), inside it 128 quads of 4 time steps.
     const int gw = __builtin_amdgcn_readfirstlane(tid >> 7);
@@ -161,9 +161,11 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, e, gbad ? 0 : sb4 + j * cs * 4, 0));
+        if (KW == 3) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            xh[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, eh, gbad ? 0 : sb4 + j * cs * 4, 0));
+            for (int j = 0; j < 8; ++j)
+                xh[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, eh, gbad ? 0 : sb4 + j * cs * 4, 0));
+        }
         if (HAS_ISC) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -189,10 +191,10 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
             buf[xslot + (k == 3 ? 1 : (k + 1) * PI)] = pack8(v);           // unit 4*i4 + 1 + k
         }
     };
-    auto store_halo = [&](bf16x8* buf) { if (!(ABL & 8)) buf[hslot] = pack8(xh); };
+    auto store_halo = [&](bf16x8* buf) { if (KW == 3 && !(ABL & 8)) buf[hslot] = pack8(xh); };
     auto dma_w = [&](int kh, int ci0, bf16x8* buf) {
         if (ABL & 32) return;
-        const int so = ((kh * 3) * g.GP + (ci0 >> 3)) * g.CoutP * 16;      // bytes, scalar
+        const int so = ((kh * KW) * g.GP + (ci0 >> 3)) * g.CoutP * 16;     // bytes, scalar
 #pragma unroll
         for (int jj = 0; jj < WJ; ++jj)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(buf + XSZ + jj * NTH + wave * 64), 16, wvo[jj], so, 0, 0);
@@ -230,7 +232,9 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
     store_halo(smem);
     advance(kA, cA);
     issue_act(kA, cA);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the weight DMA of slab 0 (older than the 16 raw loads of slab 1)
+    // the weight DMA of slab 0 is older than the raw loads of slab 1 (16 with the halo, 8 without)
+    if (KW == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __syncthreads();
 
     // MFMA schedule of a slab: NGP channel-group pairs x 3 time taps; tap kw of pair gp multiplies A(gp, kw) with
@@ -255,33 +259,46 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
             acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c][1], sv[(gp) & 1][q + (kw)], acc[1][q], 0, 0, 0); \
     }                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);
-        READ_S(0, 0) READ_S(0, 1) READ_A(0, 0, 0) READ_S(0, 2) READ_S(0, 3)
+        if (KW == 3) { READ_S(0, 0) }
+        READ_S(0, 1) READ_A(0, 0, 0) READ_S(0, 2) READ_S(0, 3)
+        if (KW == 1) { READ_S(0, 4) }              // one tap = the centre one: units tt + 1 .. tt + 4
         dma_w(kA, cA, Xw);                         // weights of slab j+1: issued BEFORE this slab's raw loads (see the wait below)
-        // pair 0, tap 0
-        READ_S(0, 4) READ_A(1, 0, 1)
-        store_main(Xw, 0, 2);
-        MFMA_TAP(0, 0, 0)
-        // pair 0, tap 1
-        READ_S(0, 5) READ_A(0, 0, 2)
-        store_main(Xw, 2, 4);
-        store_halo(Xw);
-        MFMA_TAP(1, 0, 1)
-        // pair 0, tap 2: the staging registers are free again -> raw loads of slab j+2
-        if (NGP == 2) { READ_S(1, 0) READ_S(1, 1) READ_A(1, 1, 0) }
-        advance(kA, cA);
-        issue_act(kA, cA);
-        MFMA_TAP(0, 0, 2)
-        if (NGP == 2) {
-            READ_S(1, 2) READ_S(1, 3)
-            READ_S(1, 4) READ_A(0, 1, 1)
-            MFMA_TAP(1, 1, 0)
-            READ_S(1, 5) READ_A(1, 1, 2)
-            MFMA_TAP(0, 1, 1)
-            MFMA_TAP(1, 1, 2)
+        if constexpr (KW == 3) {
+            // pair 0, tap 0
+            READ_S(0, 4) READ_A(1, 0, 1)
+            store_main(Xw, 0, 2);
+            MFMA_TAP(0, 0, 0)
+            // pair 0, tap 1
+            READ_S(0, 5) READ_A(0, 0, 2)
+            store_main(Xw, 2, 4);
+            store_halo(Xw);
+            MFMA_TAP(1, 0, 1)
+            // pair 0, tap 2: the staging registers are free again -> raw loads of slab j+2
+            if (NGP == 2) { READ_S(1, 0) READ_S(1, 1) READ_A(1, 1, 0) }
+            advance(kA, cA);
+            issue_act(kA, cA);
+            MFMA_TAP(0, 0, 2)
+            if (NGP == 2) {
+                READ_S(1, 2) READ_S(1, 3)
+                READ_S(1, 4) READ_A(0, 1, 1)
+                MFMA_TAP(1, 1, 0)
+                READ_S(1, 5) READ_A(1, 1, 2)
+                MFMA_TAP(0, 1, 1)
+                MFMA_TAP(1, 1, 2)
+            }
+        } else {
+            // (1,1) kernel: one tap per pair, S(0..3) only; the slab is staging-bound, the MFMAs ride along
+            if (NGP == 2) { READ_S(1, 1) READ_S(1, 2) READ_A(1, 1, 0) READ_S(1, 3) READ_S(1, 4) }
+            store_main(Xw, 0, 4);
+            advance(kA, cA);
+            issue_act(kA, cA);
+            MFMA_TAP(0, 0, 1)
+            if (NGP == 2) { MFMA_TAP(1, 1, 1) }
         }
         // Vector-memory operations retire in order: WJ weight DMAs, then this slab's 16 raw loads.  At most 16
         // outstanding = this wave's share of the weight slab is in LDS; the barrier then publishes it to the other waves.
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (KW == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         if (!(ABL & 16)) __syncthreads();
         cur ^= 1;
     }
@@ -331,7 +348,7 @@ inline int ilog2_ceil_b(int v) {
     return l;
 }
 
-template <int G>
+template <int G, int KW>
 void launch_bf16p(const babe_conv_args& a, Bf16pGeom g, const unsigned short* wq, hipStream_t s) {
     constexpr int BN = 32 * G, NTH = 128 * G;
     g.pt_log2 = ilog2_ceil_b(a.T);
@@ -344,18 +361,18 @@ void launch_bf16p(const babe_conv_args& a, Bf16pGeom g, const unsigned short* wq
     g.ncb = cdiv(g.CoutP, BN);
     g.total = g.tiles_t * g.tiles_f * g.ncb * a.B;
     dim3 grid(8 * ((g.total + 7) / 8));
-    constexpr int WJ = (3 * G * BN + NTH - 1) / NTH;
+    constexpr int WJ = (KW * G * BN + NTH - 1) / NTH;
     const size_t lds = 2 * (size_t)(G * 640 + WJ * NTH + 4) * 16;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, KW, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, KW, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    if (a.in_scale) hipLaunchKernelGGL((conv_bf16p_kernel<G, true>), grid, dim3(NTH), lds, s, a, g, wq);
-    else hipLaunchKernelGGL((conv_bf16p_kernel<G, false>), grid, dim3(NTH), lds, s, a, g, wq);
+    if (a.in_scale) hipLaunchKernelGGL((conv_bf16p_kernel<G, KW, true>), grid, dim3(NTH), lds, s, a, g, wq);
+    else hipLaunchKernelGGL((conv_bf16p_kernel<G, KW, false>), grid, dim3(NTH), lds, s, a, g, wq);
 }
 
 }  // namespace
@@ -364,7 +381,7 @@ void launch_bf16p(const babe_conv_args& a, Bf16pGeom g, const unsigned short* wq
 int babe_conv2d_bf16p_supported(const babe_conv_args& a) {
     static const char* ov = getenv("BABE_CONV_BF16P");
     if (ov && ov[0] == '0') return 0;
-    if (a.KW != 3 || (a.T & 3) || (a.Cin & 7) || a.Cout <= 32) return 0;
+    if (!((a.KW == 3) || (a.KW == 1 && a.KH == 1)) || (a.T & 3) || (a.Cin & 7) || a.Cout <= 32) return 0;
     if (a.in2 && (a.cin_split % 32 != 0)) return 0;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (!al16(a.out) || (a.out_bs & 3) || (a.out_cs & 3)) return 0;                   // 16-byte epilogue vectors
@@ -373,7 +390,7 @@ int babe_conv2d_bf16p_supported(const babe_conv_args& a) {
     const int split = a.in2 ? a.cin_split : a.Cin;
     if ((long)split * a.in_cs >= lim) return 0;
     if (a.in2 && (long)(a.Cin - split) * a.in2_cs >= lim) return 0;
-    if ((long)a.KH * 3 * ((a.Cin + 15) / 16 * 2) * ((a.Cout + 31) / 32 * 32) * 16 >= 0x7fffffffL) return 0;
+    if ((long)a.KH * a.KW * ((a.Cin + 15) / 16 * 2) * ((a.Cout + 31) / 32 * 32) * 16 >= 0x7fffffffL) return 0;
     return 1;
 }
 
@@ -381,7 +398,12 @@ int babe_conv2d_bf16p_launch(const babe_conv_args& a, const unsigned short* wq, 
     Bf16pGeom g;
     g.GP = (a.Cin + 15) / 16 * 2;
     g.CoutP = (a.Cout + 31) / 32 * 32;
-    if (g.CoutP == 64) launch_bf16p<2>(a, g, wq, s);      //  64 co x 512 positions, 4 waves, two workgroups per CU
-    else launch_bf16p<4>(a, g, wq, s);                    // 128 co x 512 positions, 8 waves
+    if (a.KW == 3) {
+        if (g.CoutP == 64) launch_bf16p<2, 3>(a, g, wq, s);      //  64 co x 512 positions, 4 waves, two workgroups per CU
+        else launch_bf16p<4, 3>(a, g, wq, s);                    // 128 co x 512 positions, 8 waves
+    } else {
+        if (g.CoutP == 64) launch_bf16p<2, 1>(a, g, wq, s);
+        else launch_bf16p<4, 1>(a, g, wq, s);
+    }
     return 0;
 }

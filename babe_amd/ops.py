@@ -37,9 +37,13 @@ class PackedConv:
         self.precision = precision
         self.nt = nt
         self.splits = PRECISIONS[precision]
-        # HBM-bound shapes gain nothing from bf16 MFMA: (1,1) kernels and convs with <= 4 channels on one side run on the
-        # fp32 kernels (all-DMA (1,1) kernel, few-channel kernels) whatever the requested precision - exact AND faster.
-        if self.splits and BF16_HBM_F32 and (w.shape[2] * w.shape[3] == 1 or min(w.shape[0], w.shape[1]) <= 4):
+        # Shapes that gain nothing from bf16 MFMA run on the fp32 kernels whatever the requested precision (exact AND at
+        # least as fast): convs with <= 4 channels on one side (few-channel kernels), (1,1) kernels with fewer than 32
+        # channels on one side (HBM-bound: all-DMA kernel), and every (1,1) kernel of the bf16x3 mode.  Wide (1,1) kernels are
+        # MFMA-bound in fp32 (up to 85 flop/B) and take the pipelined bf16 kernel under 'bf16'.
+        k11 = w.shape[2] * w.shape[3] == 1
+        if self.splits and BF16_HBM_F32 and (min(w.shape[0], w.shape[1]) <= 4 or
+                                             (k11 and (self.splits == 2 or min(w.shape[0], w.shape[1]) < 32))):
             self.splits = 0
         if self.splits:
             self._init_bf16(w)

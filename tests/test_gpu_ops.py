@@ -382,3 +382,49 @@ def test_conv2d_bf16_pipelined_vs_rounded_operands(ops, B, C1, C2, Cout, Fq, T, 
     ops.conv2d(gy.cuda(), pc, gx, dil=dil, transpose=True, in_scale=isc.cuda())
     assert dispatch_counts()["conv_bf16p"] == c0 + 2
     assert rel(gx, gref) < 3e-6
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,Fq,T", [
+    (2, 64, 64, 64, 64, 1024),         # two sources, 64-channel tile
+    (1, 96, 0, 256, 40, 36),           # two channel blocks, T < tile
+    (2, 256, 256, 128, 33, 64),        # wide two-source input (decoder proj_in), ragged F
+    (1, 72, 0, 96, 9, 272),            # Cin % 32 != 0, 96 channels on the 128-channel tile
+])
+def test_conv11_bf16_pipelined_vs_rounded_operands(ops, B, C1, C2, Cout, Fq, T):
+    """(1,1) convs on the pipelined bf16 kernel (one tap, no halo): exact conv of the bf16-rounded operands, forward with
+    residual / gate epilogue and input-VJP with the folded scale accumulated in place (the decoder's proj_in VJP)."""
+    from babe_amd._lib import dispatch_counts
+    g = torch.Generator().manual_seed(C1 + Cout + T)
+    Cin = C1 + C2
+    x = torch.randn(B, Cin, Fq, T, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    res = torch.randn(B, Cout, Fq, T, generator=g)
+    osc = torch.randn(B, Cout, generator=g)
+    rb = lambda t: t.to(torch.bfloat16).double()
+    ref = 0.7 * UN.conv_same(rb(x), rb(w)) * osc[:, :, None, None].double() + 0.3 * res.double()
+    pc = ops.PackedConv(w.cuda(), "bf16")
+    assert pc.splits == 1
+    xc = x.cuda()
+    x1, x2 = (xc[:, :C1].contiguous(), xc[:, C1:].contiguous()) if C2 else (xc, None)
+    o = res.cuda().clone()
+    c0 = dispatch_counts()["conv_bf16p"]
+    ops.conv2d(x1, pc, o, x2=x2, res=o, oscale=osc.cuda(), alpha=0.7, rbeta=0.3)
+    assert dispatch_counts()["conv_bf16p"] == c0 + 1
+    assert rel(o, ref) < 3e-6
+    gy = torch.randn(B, Cout, Fq, T, generator=g)
+    isc = torch.randn(B, Cout, generator=g)
+    g0 = torch.randn(B, Cin, Fq, T, generator=g)
+    gref = 0.5 * UN.conv_same(rb(gy * isc[:, :, None, None]), rb(w.transpose(0, 1))) + g0.double()
+    gx = g0.cuda().clone()
+    ops.conv2d(gy.cuda(), pc, gx, transpose=True, in_scale=isc.cuda(), res=gx, alpha=0.5, rbeta=1.0)
+    assert dispatch_counts()["conv_bf16p"] == c0 + 2
+    assert rel(gx, gref) < 3e-6
+
+
+def test_bf16_precision_routes_hbm_bound_convs_to_fp32_kernels(ops):
+    w = torch.randn(2, 64, 1, 1).cuda()
+    assert ops.PackedConv(w, "bf16").splits == 0 and ops.PackedConv(w.transpose(0, 1).contiguous(), "bf16").splits == 0
+    assert ops.PackedConv(torch.randn(64, 2, 5, 3).cuda(), "bf16").splits == 0            # pyramid conv
+    assert ops.PackedConv(torch.randn(128, 64, 1, 1).cuda(), "bf16").splits == 1
+    assert ops.PackedConv(torch.randn(128, 64, 1, 1).cuda(), "bf16x3").splits == 0
+    assert ops.PackedConv(torch.randn(128, 64, 5, 3).cuda(), "bf16x3").splits == 2
