@@ -49,6 +49,10 @@ _SIGS = {
     "babe_gn_partial": [_P, _P, _I, _I, _L, _I, _P],
     "babe_gn_finalize": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _L, _I, _F, _P],
     "babe_scale_gelu": [_P, _P, _P, _I, _I, _L, _P],
+    "babe_units_size": [_I, _I, _I],
+    "babe_scale_gelu_units": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "babe_conv2d_bf16_units_supported": [C.POINTER(ConvArgs)],
+    "babe_conv2d_bf16_units": [C.POINTER(ConvArgs), _P, _P],
     "babe_gn_bwd_partial": [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "babe_gn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _L, _I, _F, _P],
     "babe_resample": [_P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P],
@@ -79,6 +83,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = sig
             fn.restype = C.c_int
+        L.babe_units_size.restype = C.c_long
         L.babe_prof_nslots.restype = C.c_int
         L.babe_prof_slot_name.restype = C.c_char_p
         L.babe_prof_slot_name.argtypes = [_I]

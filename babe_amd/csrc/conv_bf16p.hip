@@ -45,7 +45,7 @@ constexpr unsigned OOB = 0x80000000u;      // beyond every descriptor's num_reco
 #define ABL 0
 #endif
 
-template <int G, int KW, bool HAS_ISC>
+template <int G, int KW, bool HAS_ISC, bool UNITS = false>
 __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(babe_conv_args a, Bf16pGeom g,
                                                                                const unsigned short* __restrict__ wq) {
 #if __HIP_DEVICE_COMPILE__      // buffer-descriptor builtins exist in the device pass only
@@ -64,6 +64,9 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
     const int PR = 1 << g.pr_log2;
     const int PI = (PT >> 2) + 1;                     // units per plane and row
     const int RU = 4 * PI;                            // units per row
+    // UNITS: the activations arrive as bf16 units (babe_scale_gelu_units) and are copied by LDS-DMA, which writes
+    // consecutive lanes to consecutive LDS slots: the channel groups are packed densely (PR*RU units each)
+    const int xchp = UNITS ? PR * RU : XCHP;
     // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id; tiles that read the same input rows
     // (the two channel blocks of a tile, then the frequency-neighbours of a time column) are given to ONE XCD as a
     // contiguous chunk of the list [batch][time tile][row tile][channel block], so the five-tap re-reads hit that XCD's L2.
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
     const int xspat4 = ((f0 + srow) * a.T + st) * 4;
     const unsigned xcolbad = st < a.T ? 0u : OOB;
     // units 4*i4 + 1 .. 4*i4 + 4 of the row: planes 1, 2, 3 at index i4 and plane 0 at index i4 + 1
-    const int xslot = gw * XCHP + srow * RU + i4;
+    const int xslot = gw * xchp + srow * RU + i4;
     // halo: lanes lt < 2*PR of every group own (row, side) = (lt >> 1, lt & 1): unit 0 (plane 0, index 0) or unit PT + 1
     // (plane 1, index PT / 4)
     const bool hl = lt < 2 * PR;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
     const int ht = (lt & 1) ? t0 + PT : t0 - 1;
     const int hspat4 = ((f0 + hrow) * a.T + ht) * 4;
     const unsigned hbad = (hl && ht >= 0 && ht < a.T) ? 0u : OOB;
-    const int hslot = hl ? gw * XCHP + hrow * RU + ((lt & 1) ? PI + (PT >> 2) : 0) : XSZ + WJ * NTH;
+    const int hslot = hl ? gw * xchp + hrow * RU + ((lt & 1) ? PI + (PT >> 2) : 0) : XSZ + WJ * NTH;
     int wvo[WJ];
 #pragma unroll
     for (int jj = 0; jj < WJ; ++jj) {
@@ -130,6 +133,41 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
         const int co_l = rem - gl * BN;
         wvo[jj] = (int)((unsigned)((((kw * g.GP + gl) * g.CoutP) + co0 + co_l) * 16) | (idx < NWU ? 0u : OOB));
     }
+
+    // UNITS: X-image DMA tasks.  Slot s = tid + k*NTH of the dense image [group][row][plane][index] <- the unit at
+    // [group][f][plane][t0/4 + index] of the tensor; entries beyond T/4 and slots beyond the image read as zeros.
+    constexpr int XJ = XSZ / NTH;
+    int xvo[UNITS ? XJ : 1], xrw[UNITS ? XJ : 1];
+    const int PIg = (a.T >> 2) + 1;                    // entries per plane of a tensor row
+    if (UNITS) {
+#pragma unroll
+        for (int k = 0; k < XJ; ++k) {
+            const int sl = tid + k * NTH;
+            const int gl = sl / xchp;
+            const int r = sl - gl * xchp;
+            const int row = r / RU;
+            const int rr = r - row * RU;
+            const int pl = rr / PI;
+            const int ix = rr - pl * PI;
+            const int e = (t0 >> 2) + ix;
+            const bool ok = gl < G && e < PIg;
+            xrw[k] = f0 + row;
+            xvo[k] = (int)((unsigned)((gl * (int)a.in_cs + ((f0 + row) * 4 + pl) * PIg + e) * 16) | (ok ? 0u : OOB));
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(UNITS ? reinterpret_cast<const char*>(a.in) + (long)b * a.in_bs * 16 : reinterpret_cast<const char*>(a.in)), 0,
+        UNITS ? (a.Cin >> 3) * (int)a.in_cs * 16 : 0, 0x00020000);
+    auto dma_x = [&](int kh, int ci0, bf16x8* buf) {
+        const int foff = (kh - khc) * a.dil;
+        const int so = ((ci0 >> 3) * (int)a.in_cs + foff * 4 * PIg) * 16;      // scalar; added to the LANE offset (range-checked)
+#pragma unroll
+        for (int k = 0; k < (UNITS ? XJ : 0); ++k) {
+            const int fr = xrw[k] + foff;
+            const unsigned e = (unsigned)(xvo[k] + so) | ((unsigned)(fr | (a.F - 1 - fr)) & OOB) | ((unsigned)xvo[k] & OOB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, LDS_PTR(buf + k * NTH + wave * 64), 16, e, 0, 0, 0);
+        }
+    };
 
     f32x16 acc[NT][NP];
 #pragma unroll
@@ -144,7 +182,7 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
     float xh[8], xsc[8];
 
     auto issue_act = [&](int kh, int ci0) {
-        if (ABL & 1) return;
+        if ((ABL & 1) || UNITS) return;
         const int foff = (kh - khc) * a.dil;
         const bool s2 = ci0 >= split;
         const int nch = s2 ? a.Cin - split : split;
@@ -182,7 +220,7 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
         return o;
     };
     auto store_main = [&](bf16x8* buf, int k0, int k1) {
-        if (ABL & 8) return;
+        if ((ABL & 8) || UNITS) return;
 #pragma unroll
         for (int k = k0; k < k1; ++k) {
             float v[8];
@@ -191,7 +229,7 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
             buf[xslot + (k == 3 ? 1 : (k + 1) * PI)] = pack8(v);           // unit 4*i4 + 1 + k
         }
     };
-    auto store_halo = [&](bf16x8* buf) { if (KW == 3 && !(ABL & 8)) buf[hslot] = pack8(xh); };
+    auto store_halo = [&](bf16x8* buf) { if (KW == 3 && !(ABL & 8) && !UNITS) buf[hslot] = pack8(xh); };
     auto dma_w = [&](int kh, int ci0, bf16x8* buf) {
         if (ABL & 32) return;
         const int so = ((kh * KW) * g.GP + (ci0 >> 3)) * g.CoutP * 16;     // bytes, scalar
@@ -221,20 +259,28 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
     const int tt0 = p0 & (PT - 1);
     int boff[6];
 #pragma unroll
-    for (int m = 0; m < 6; ++m) boff[m] = h * XCHP + prow * RU + (m & 3) * PI + (tt0 >> 2) + (m >> 2);
+    for (int m = 0; m < 6; ++m) boff[m] = h * xchp + prow * RU + (m & 3) * PI + (tt0 >> 2) + (m >> 2);
+    const int gpo = 2 * xchp;                        // second channel-group pair
     const int aoff = XSZ + h * BN + wr * (NT * 32) + l31;
 
     // ---- prologue: slab 0 into buffer 0, raw loads of slab 1 in flight
     int kA = kh_lo, cA = 0;
-    issue_act(kA, cA);
-    dma_w(kA, cA, smem);
-    store_main(smem, 0, 4);
-    store_halo(smem);
-    advance(kA, cA);
-    issue_act(kA, cA);
-    // the weight DMA of slab 0 is older than the raw loads of slab 1 (16 with the halo, 8 without)
-    if (KW == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (UNITS) {
+        dma_w(kA, cA, smem);
+        dma_x(kA, cA, smem);
+        advance(kA, cA);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        issue_act(kA, cA);
+        dma_w(kA, cA, smem);
+        store_main(smem, 0, 4);
+        store_halo(smem);
+        advance(kA, cA);
+        issue_act(kA, cA);
+        // the weight DMA of slab 0 is older than the raw loads of slab 1 (16 with the halo, 8 without)
+        if (KW == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
     __syncthreads();
 
     // MFMA schedule of a slab: NGP channel-group pairs x 3 time taps; tap kw of pair gp multiplies A(gp, kw) with
@@ -250,7 +296,7 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
         bf16x8* Xw = smem + (cur ^ 1) * BUF;
 #define READ_A(c, gp, kw) if (!(ABL & 4) || j == 0) \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) av[c][nt] = Xs[aoff + ((kw) * G + 2 * (gp)) * BN + nt * 32];
-#define READ_S(gp, m) if (!(ABL & 4) || j == 0) sv[(gp) & 1][m] = Xs[boff[m] + 2 * (gp) * XCHP];
+#define READ_S(gp, m) if (!(ABL & 4) || j == 0) sv[(gp) & 1][m] = Xs[boff[m] + (gp) * gpo];
 #define MFMA_TAP(c, gp, kw)                                                                                   \
     if (!(ABL & 2)) {                                                                                         \
         _Pragma("unroll") for (int q = 0; q < NP; ++q)                                                        \
@@ -263,6 +309,7 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
         READ_S(0, 1) READ_A(0, 0, 0) READ_S(0, 2) READ_S(0, 3)
         if (KW == 1) { READ_S(0, 4) }              // one tap = the centre one: units tt + 1 .. tt + 4
         dma_w(kA, cA, Xw);                         // weights of slab j+1: issued BEFORE this slab's raw loads (see the wait below)
+        if (UNITS) dma_x(kA, cA, Xw);              // ... and its activation units: both operands by DMA, no staging registers
         if constexpr (KW == 3) {
             // pair 0, tap 0
             READ_S(0, 4) READ_A(1, 0, 1)
@@ -297,7 +344,8 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
         }
         // Vector-memory operations retire in order: WJ weight DMAs, then this slab's 16 raw loads.  At most 16
         // outstanding = this wave's share of the weight slab is in LDS; the barrier then publishes it to the other waves.
-        if (KW == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (UNITS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (KW == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         if (!(ABL & 16)) __syncthreads();
         cur ^= 1;
@@ -348,7 +396,7 @@ inline int ilog2_ceil_b(int v) {
     return l;
 }
 
-template <int G, int KW>
+template <int G, int KW, bool UNITS = false>
 void launch_bf16p(const babe_conv_args& a, Bf16pGeom g, const unsigned short* wq, hipStream_t s) {
     constexpr int BN = 32 * G, NTH = 128 * G;
     g.pt_log2 = ilog2_ceil_b(a.T);
@@ -365,14 +413,14 @@ void launch_bf16p(const babe_conv_args& a, Bf16pGeom g, const unsigned short* wq
     const size_t lds = 2 * (size_t)(G * 640 + WJ * NTH + 4) * 16;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, KW, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, KW, true, UNITS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, KW, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, KW, false, UNITS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    if (a.in_scale) hipLaunchKernelGGL((conv_bf16p_kernel<G, KW, true>), grid, dim3(NTH), lds, s, a, g, wq);
-    else hipLaunchKernelGGL((conv_bf16p_kernel<G, KW, false>), grid, dim3(NTH), lds, s, a, g, wq);
+    if (a.in_scale) hipLaunchKernelGGL((conv_bf16p_kernel<G, KW, true, UNITS>), grid, dim3(NTH), lds, s, a, g, wq);
+    else hipLaunchKernelGGL((conv_bf16p_kernel<G, KW, false, UNITS>), grid, dim3(NTH), lds, s, a, g, wq);
 }
 
 }  // namespace
@@ -406,4 +454,36 @@ int babe_conv2d_bf16p_launch(const babe_conv_args& a, const unsigned short* wq, 
         else launch_bf16p<4, 1>(a, g, wq, s);
     }
     return 0;
+}
+
+/* Same conv with the activations already in bf16 "units" (babe_scale_gelu_units): a->in = unit tensor, a->in_bs / a->in_cs =
+ * units per batch item / per 8-channel group; no second source, no in_scale.  Both operands travel by LDS-DMA. */
+extern "C" int babe_conv2d_bf16_units_supported(const babe_conv_args* ap) {
+    if (!ap) return 0;
+    const babe_conv_args& a = *ap;
+    static const char* ov = getenv("BABE_CONV_BF16U");
+    if (ov && ov[0] == '0') return 0;
+    if (a.KH != 5 || a.KW != 3 || (a.T & 3) || (a.Cin & 7) || a.Cout <= 32 || a.in2 || a.in_scale) return 0;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (!al16(a.in) || !al16(a.out) || (a.out_bs & 3) || (a.out_cs & 3)) return 0;
+    if (a.res && (!al16(a.res) || (a.res_bs & 3) || (a.res_cs & 3))) return 0;
+    if ((long)(a.Cin >> 3) * a.in_cs * 16 >= 0x7fffffffL) return 0;
+    if ((long)a.KH * 3 * ((a.Cin + 15) / 16 * 2) * ((a.Cout + 31) / 32 * 32) * 16 >= 0x7fffffffL) return 0;
+    return 1;
+}
+
+extern "C" int babe_conv2d_bf16_units(const babe_conv_args* ap, const void* w_bf16, void* stream) {
+    BABE_CHECK_ARG(ap && w_bf16, "conv2d_bf16_units: null args");
+    BABE_CHECK_ARG(babe_conv2d_bf16_units_supported(ap), "conv2d_bf16_units: unsupported problem (see babe_conv2d_bf16_units_supported)");
+    const babe_conv_args& a = *ap;
+    BABE_CHECK_ARG(a.in_cs == (long)a.F * 4 * (a.T / 4 + 1), "conv2d_bf16_units: in_cs %ld is not F*4*(T/4+1)", a.in_cs);
+    Bf16pGeom g;
+    g.GP = (a.Cin + 15) / 16 * 2;
+    g.CoutP = (a.Cout + 31) / 32 * 32;
+    const double flops = babe_conv_flops(a);
+    BabeProfScope prof(BABE_SLOT_CONV_BF16P, babe_conv_bytes(a) - 2.0 * a.B * a.Cin * (double)a.F * a.T, flops, flops, stream);
+    if (g.CoutP == 64) launch_bf16p<2, 3, true>(a, g, (const unsigned short*)w_bf16, (hipStream_t)stream);
+    else launch_bf16p<4, 3, true>(a, g, (const unsigned short*)w_bf16, (hipStream_t)stream);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
 }

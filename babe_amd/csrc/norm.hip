@@ -122,6 +122,52 @@ __global__ __launch_bounds__(256) void scale_gelu_kernel(const float* __restrict
         for (long i = nv * 4 + threadIdx.x; i < hw; i += blockDim.x) a[base + i] = gelu_f(x[base + i] * sc);
 }
 
+// scale*GELU written as bf16 "units" for the pipelined bf16 conv (conv_bf16p.hip, UNITS variant): a unit = 8 consecutive
+// channels of one (f, t) as 8 bf16 = 16 bytes - exactly one lane's MFMA B-operand fragment.  Layout
+// [B][C/8][F][4 planes][T/4 + 1] units, plane p entry j = time step 4j + p - 1 (so a conv tile's operand runs S(m) are
+// contiguous in HBM and travel by LDS-DMA unchanged); t = -1 and t >= T are stored as zeros (the conv's time padding).
+// One thread = 8 channels x 4 time steps: eight 16-byte loads, four 16-byte stores, all coalesced along t.
+// grid: (blocks over F * T/4, C/8, B)
+typedef __bf16 bf16x8_n __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void scale_gelu_units_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                               bf16x8_n* __restrict__ au, int C, int F, int T) {
+    const int g = blockIdx.y, b = blockIdx.z;
+    const int Q = T >> 2, PI = Q + 1;
+    const long hw = (long)F * T;
+    float sc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sc[j] = scale[b * C + 8 * g + j];
+    const float* xb = x + ((long)b * C + 8 * g) * hw;
+    bf16x8_n* ab = au + ((long)b * (C >> 3) + g) * F * 4 * PI;
+    const long nq = (long)F * Q;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(i / Q), q = (int)(i - (long)f * Q);
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(xb + j * hw + (long)f * T + 4 * q);
+        bf16x8_n u0, u1, u2, u3, z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            u0[j] = (__bf16)gelu_f(v[j].x * sc[j]);
+            u1[j] = (__bf16)gelu_f(v[j].y * sc[j]);
+            u2[j] = (__bf16)gelu_f(v[j].z * sc[j]);
+            u3[j] = (__bf16)gelu_f(v[j].w * sc[j]);
+            z[j] = (__bf16)0.f;
+        }
+        bf16x8_n* row = ab + (long)f * 4 * PI;
+        row[1 * PI + q] = u0;          // t = 4q     -> plane 1, entry q
+        row[2 * PI + q] = u1;          // t = 4q + 1 -> plane 2
+        row[3 * PI + q] = u2;          // t = 4q + 2 -> plane 3
+        row[q + 1] = u3;               // t = 4q + 3 -> plane 0, entry q + 1
+        if (q == 0) row[0] = z;        // t = -1
+        if (q == Q - 1) {              // t = T, T + 1, T + 2
+            row[1 * PI + Q] = z;
+            row[2 * PI + Q] = z;
+            row[3 * PI + Q] = z;
+        }
+    }
+}
+
 // grid: (S, B*G).  A group is cg channels of hw elements, contiguous: n = cg*hw.
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dadu,
                                                              const float* __restrict__ scale,
@@ -232,6 +278,23 @@ extern "C" int babe_scale_gelu(const float* x, const float* scale, float* a, int
     if (bx < 1) bx = 1;
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(scale_gelu_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, scale, a, C, hw);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" long babe_units_size(int C, int F, int T) { return (long)(C / 8) * F * 4 * (T / 4 + 1); }     // 16-byte units per batch item
+
+extern "C" int babe_scale_gelu_units(const float* x, const float* scale, void* au, int B, int C, int F, int T,
+                                     void* stream) {
+    BABE_CHECK_ARG(x && scale && au && B > 0 && C > 0 && F > 0 && T > 0, "scale_gelu_units: bad arguments");
+    BABE_CHECK_ARG(T % 4 == 0 && C % 8 == 0, "scale_gelu_units: T=%d C=%d unsupported (need T %% 4 == 0, C %% 8 == 0)", T, C);
+    BABE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)au & 15) == 0, "scale_gelu_units: unaligned pointer");
+    BabeProfScope prof(BABE_SLOT_SCALE_GELU, 6.0 * B * C * (double)F * T, 0, 0, stream);
+    int bx = cdiv((long)F * (T / 4), 256 * 2);
+    if (bx < 1) bx = 1;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(scale_gelu_units_kernel, dim3(bx, C / 8, B), dim3(256), 0, (hipStream_t)stream, x, scale,
+                       (bf16x8_n*)au, C, F, T);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

@@ -113,6 +113,13 @@ class UnetEngine:
             self._scratch[name] = t
         return t[:numel]
 
+    def scratch_i16(self, name, numel):
+        t = self._scratch.get(name)
+        if t is None or t.numel() < numel:
+            t = torch.empty(numel, device=self.dev, dtype=torch.int16)
+            self._scratch[name] = t
+        return t[:numel]
+
     def embed(self, cnoise):
         """cnoise [B,1] -> FiLM vectors for every layer [B, J] (RFF_MLP_Block + all affine/gate Linears)."""
         h = ops.rff(cnoise, self.rff_freq)
@@ -134,13 +141,22 @@ class UnetEngine:
             assert x2 is None
             z = x if x.is_contiguous() else ops.axpby(x, self.buf(B, N, Fq, T))
         saved = []
-        a = self.scratch("a", B * N * Fq * T).view(B, N, Fq, T)
+        # precision='bf16': the GELU output goes to the conv as bf16 units (half the bytes, both conv operands by LDS-DMA)
+        units = blk.nd > 0 and ops.units_ok(blk.H[0], N, N, T) and z.is_contiguous()
+        if units:
+            au = self.scratch_i16("au", B * ops.lib().babe_units_size(N, Fq, T) * 8)
+        else:
+            a = self.scratch("a", B * N * Fq * T).view(B, N, Fq, T)
         for d in range(blk.nd):
             aoff, goff = blk.film_off[d]
             stats, scale = ops.gn_scale(z, blk.gamma[d], self._film(film, aoff, N))
-            ops.scale_gelu(z, scale, a)
             gate = self._film(film, goff, N).contiguous()
-            znew = ops.conv2d(a, blk.H[d], self.buf(B, N, Fq, T), dil=blk.dil(d), res=z, oscale=gate, alpha=RS2, rbeta=RS2)
+            if units:
+                ops.scale_gelu_units(z, scale, au)
+                znew = ops.conv2d_units(au, blk.H[d], self.buf(B, N, Fq, T), N, dil=blk.dil(d), res=z, oscale=gate, alpha=RS2, rbeta=RS2)
+            else:
+                ops.scale_gelu(z, scale, a)
+                znew = ops.conv2d(a, blk.H[d], self.buf(B, N, Fq, T), dil=blk.dil(d), res=z, oscale=gate, alpha=RS2, rbeta=RS2)
             saved.append((z, stats, scale, gate))
             z = znew
         if blk.proj_out is not None:

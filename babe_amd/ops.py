@@ -165,6 +165,47 @@ def scale_gelu(x, scale, out):
     return out
 
 
+UNITS = os.environ.get("BABE_CONV_BF16U", "1") != "0"
+
+
+def units_ok(pc, Cin, Cout, T):
+    """True if the forward of this (5,3) conv can take its input as bf16 units (csrc/conv_bf16p.hip, UNITS variant)."""
+    return UNITS and pc.splits == 1 and pc.KH == 5 and pc.KW == 3 and T % 4 == 0 and Cin % 8 == 0 and Cout > 32
+
+
+def scale_gelu_units(x, scale, au):
+    """GroupNorm-scale * GELU of x [B,C,F,T], written as bf16 units into the int16 buffer `au` (>= B*units_size*8)."""
+    B, Cc, F, T = x.shape
+    assert x.is_contiguous() and au.dtype == torch.int16 and au.is_contiguous()
+    assert au.numel() >= B * lib().babe_units_size(Cc, F, T) * 8
+    check(lib().babe_scale_gelu_units(ptr(x), ptr(scale), ptr(au), B, Cc, F, T, stream()), "scale_gelu_units")
+    return au
+
+
+def conv2d_units(au, pc, out, Cin, dil=1, res=None, oscale=None, alpha=1.0, rbeta=1.0):
+    """out = alpha * conv(units, w) * oscale + rbeta * res with the input given as bf16 units (scale_gelu_units)."""
+    B, Cout, F, T = out.shape
+    a = ConvArgs()
+    nu = lib().babe_units_size(Cin, F, T)
+    a.in_, a.in_bs, a.in_cs = ptr(au), nu, nu // (Cin // 8)
+    a.in2, a.in2_bs, a.in2_cs, a.cin_split = None, 0, 0, Cin
+    a.w_packed = None
+    a.out, a.out_bs, a.out_cs = _view(out)
+    if res is not None:
+        assert res.shape == out.shape
+        a.res, a.res_bs, a.res_cs = _view(res)
+    else:
+        a.res, a.res_bs, a.res_cs = None, 0, 0
+    if oscale is not None:
+        assert oscale.is_contiguous() and oscale.shape == (B, Cout)
+    a.in_scale, a.oscale = None, ptr(oscale)
+    a.alpha, a.rbeta = alpha, rbeta
+    a.B, a.Cin, a.Cout, a.F, a.T = B, Cin, Cout, F, T
+    a.KH, a.KW, a.dil = pc.KH, pc.KW, dil
+    check(lib().babe_conv2d_bf16_units(C.byref(a), ptr(pc.fwd), stream()), "conv2d_bf16_units")
+    return out
+
+
 def gn_bwd(x, da, gy, scale, stats, gx, rbeta, G=8, eps=1e-7):
     """gx = rbeta*gy + GN/FiLM/GELU input-VJP of da (gx may alias gy; da is only read)."""
     B, Cc, F, T = x.shape

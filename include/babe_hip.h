@@ -55,6 +55,18 @@ int babe_conv2d_bf16(const babe_conv_args* a, const void* w_bf16, int splits, vo
 int babe_conv_pack_weights_bf16(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
                                 int splits, void* stream);
 long babe_conv_packed_size_bf16(int Cout, int Cin, int KH, int KW, int transpose_flip, int splits);
+/* bf16 "units" path for the forward (5,3) layers under precision='bf16' (csrc/conv_bf16p.hip, UNITS variant).  The
+ * producer of a conv's input - GroupNorm scale * GELU, networks/cqtdiff+.py:472-482 - writes it as bf16 units instead of
+ * fp32: a unit = 8 consecutive channels of one (f, t) = 16 bytes = one lane's MFMA operand fragment; tensor layout
+ * [B][C/8][F][4 planes][T/4 + 1] units, plane p entry j = time step 4j + p - 1 (t = -1 and t >= T stored as zeros).
+ * babe_units_size = units per batch item.  babe_conv2d_bf16_units takes such a tensor as a->in (a->in_bs / a->in_cs = units
+ * per batch item / per 8-channel group = F*4*(T/4+1); no second source, no in_scale) and moves BOTH operands by LDS-DMA;
+ * result identical to babe_conv2d_bf16 (splits = 1) on the fp32 tensor.  Needs KH x KW = 5 x 3, T % 4 == 0, Cin % 8 == 0,
+ * Cout > 32, 16-byte aligned out / res rows (babe_conv2d_bf16_units_supported). */
+long babe_units_size(int C, int F, int T);
+int babe_scale_gelu_units(const float* x, const float* scale, void* units, int B, int C, int F, int T, void* stream);
+int babe_conv2d_bf16_units_supported(const babe_conv_args* a);
+int babe_conv2d_bf16_units(const babe_conv_args* a, const void* w_bf16, void* stream);
 /* Winograd F(2,3)-along-time variant of the exact-fp32 conv for KW == 3 (csrc/conv_wino.hip): 2/3 of the MFMA work,
  * same result up to fp32 rounding.  w_wino from babe_conv_pack_weights_wino: [KH][ceil8(Cin)][ceil32(Cout)][4].
  * babe_conv2d_wino_supported() tells whether a problem qualifies (even T, aligned rows, tileable Cout). */

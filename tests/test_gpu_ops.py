@@ -428,3 +428,37 @@ def test_bf16_precision_routes_hbm_bound_convs_to_fp32_kernels(ops):
     assert ops.PackedConv(torch.randn(128, 64, 1, 1).cuda(), "bf16").splits == 1
     assert ops.PackedConv(torch.randn(128, 64, 1, 1).cuda(), "bf16x3").splits == 0
     assert ops.PackedConv(torch.randn(128, 64, 5, 3).cuda(), "bf16x3").splits == 2
+
+
+@pytest.mark.parametrize("B,C,Fq,T,dil", [
+    (2, 64, 64, 1024, 2),      # 64-channel shape, two time tiles per row
+    (1, 96, 40, 36, 4),        # 96 channels on the 128-channel tile, T < tile (entries beyond T/4 read as zeros)
+    (1, 128, 33, 128, 16),     # ragged F, taps skipped at the borders
+    (2, 256, 70, 16, 8),       # shortest rows: 32 rows per tile
+    (1, 72, 9, 272, 1),        # Cin % 32 != 0, T not a power of two
+])
+def test_bf16_units_path_is_bit_identical_to_fp32_staging(ops, B, C, Fq, T, dil):
+    """precision='bf16' forward: GroupNorm-scale*GELU written as bf16 units (babe_scale_gelu_units) + all-DMA conv
+    (babe_conv2d_bf16_units) == scale_gelu to fp32 + the staging kernel, bit for bit (same rounding, same MFMA order)."""
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(B, C, Fq, T, generator=g).cuda()
+    sc = (torch.rand(B, C, generator=g) + 0.5).cuda()
+    w = (torch.randn(C, C, 5, 3, generator=g) / math.sqrt(C * 15)).cuda()
+    res = torch.randn(B, C, Fq, T, generator=g).cuda()
+    osc = torch.randn(B, C, generator=g).cuda()
+    pc = ops.PackedConv(w, "bf16")
+    assert ops.units_ok(pc, C, C, T)
+    a = torch.empty_like(x)
+    ops.scale_gelu(x, sc, a)
+    ref = ops.conv2d(a, pc, torch.empty_like(x), dil=dil, res=res, oscale=osc, alpha=0.7, rbeta=0.3)
+    from babe_amd._lib import lib
+    au = torch.full((B * lib().babe_units_size(C, Fq, T) * 8,), 0x7fc0, dtype=torch.int16, device="cuda")   # NaN-filled
+    ops.scale_gelu_units(x, sc, au)
+    out = ops.conv2d_units(au, pc, torch.empty_like(x), C, dil=dil, res=res, oscale=osc, alpha=0.7, rbeta=0.3)
+    assert torch.equal(out, ref)
+    # the unit tensor itself: plane p entry j = bf16(gelu(x*sc)) at t = 4j + p - 1, zeros outside [0, T)
+    u = au.view(torch.bfloat16).view(B, C // 8, Fq, 4, T // 4 + 1, 8).float()
+    full = torch.zeros(B, C // 8, Fq, T + 4, 8, device="cuda")
+    full[:, :, :, 1:T + 1] = a.to(torch.bfloat16).float().view(B, C // 8, 8, Fq, T).permute(0, 1, 3, 4, 2)
+    want = full.view(B, C // 8, Fq, T // 4 + 1, 4, 8).permute(0, 1, 2, 4, 3, 5)
+    assert torch.equal(u, want)
