@@ -96,12 +96,21 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, const float*
                                    float* __restrict__ scale, int C, int G, long n, int S, float eps) {
     const int b = blockIdx.x;
     __shared__ float rstd_sh[64];
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    // one 32-lane half-wave per group: the S partial sums are read in parallel and combined by shuffles (a serial loop of
+    // S dependent-latency loads on 8 lanes made this tiny kernel take 8 us)
+    const int sub = threadIdx.x & 31;
+    for (int g = threadIdx.x >> 5; g < G; g += blockDim.x >> 5) {
         double s0 = 0, s1 = 0;
-        for (int s = 0; s < S; ++s) {
+        for (int s = sub; s < S; s += 32) {
             s0 += part[((long)(b * G + g) * S + s) * 2];
             s1 += part[((long)(b * G + g) * S + s) * 2 + 1];
         }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 32);
+            s1 += __shfl_xor(s1, o, 32);
+        }
+        if (sub != 0) continue;
         const double mean = s0 / (double)n;
         double var = (s1 - (double)n * mean * mean) / (double)(n - 1);
         if (var < 0) var = 0;
@@ -201,17 +210,26 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
     if (end > n) end = n;
     const long base = ((long)b * C + (long)g * cg) * hw;
     double s0 = 0, s1 = 0;
-    // hw is a multiple of 4 (checked on the host) so a float4 never straddles two channels
-    for (long i = beg + (long)threadIdx.x * 4; i < end; i += (long)blockDim.x * 4) {
-        const int c = g * cg + (int)(i / hw);
-        const float sc = scale[b * C + c];
-        const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
-        float4 dv = *reinterpret_cast<const float4*>(dadu + base + i);
-        dv.x *= gelu_grad_f(xv.x * sc);
-        dv.y *= gelu_grad_f(xv.y * sc);
-        dv.z *= gelu_grad_f(xv.z * sc);
-        dv.w *= gelu_grad_f(xv.w * sc);
-        s0 += (double)sc * ((double)dv.x * xv.x + (double)dv.y * xv.y + (double)dv.z * xv.z + (double)dv.w * xv.w);
+    // hw is a multiple of 4 (checked on the host) so a float4 never straddles two channels.  Channel by channel: the
+    // scale is a scalar of the inner loop and there is no 64-bit division per element (there was: i / hw).
+    if (beg < end) {
+        const int c_lo = (int)(beg / hw), c_hi = (int)((end - 1) / hw);
+        for (int cl = c_lo; cl <= c_hi; ++cl) {
+            const long lo = beg > (long)cl * hw ? beg : (long)cl * hw;
+            const long hi = end < (long)(cl + 1) * hw ? end : (long)(cl + 1) * hw;
+            const float sc = scale[b * C + g * cg + cl];
+            double sc_sum = 0;
+            for (long i = lo + (long)threadIdx.x * 4; i < hi; i += (long)blockDim.x * 4) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+                float4 dv = *reinterpret_cast<const float4*>(dadu + base + i);
+                dv.x *= gelu_grad_f(xv.x * sc);
+                dv.y *= gelu_grad_f(xv.y * sc);
+                dv.z *= gelu_grad_f(xv.z * sc);
+                dv.w *= gelu_grad_f(xv.w * sc);
+                sc_sum += (double)dv.x * xv.x + (double)dv.y * xv.y + (double)dv.z * xv.z + (double)dv.w * xv.w;
+            }
+            s0 += (double)sc * sc_sum;
+        }
     }
     block_reduce2(s0, s1, sh);
     if (threadIdx.x == 0) part[(long)bg * S + s] = s0;
@@ -228,8 +246,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const int cg = C / G;
     const int g = c / cg;
     const long n = (long)cg * hw;
-    double S1 = 0;
-    for (int s = 0; s < S; ++s) S1 += part[(long)(b * G + g) * S + s];
+    // the S partial sums: read in parallel by the first wave (a serial loop of S loads delayed every block's start)
+    __shared__ double S1_sh;
+    if (threadIdx.x < 64) {
+        double v = 0;
+        for (int s = threadIdx.x; s < S; s += 64) v += part[(long)(b * G + g) * S + s];
+        v = wave_sum(v);
+        if (threadIdx.x == 0) S1_sh = v;
+    }
+    __syncthreads();
+    const double S1 = S1_sh;
     const float mean = stats[(b * G + g) * 3 + 0];
     const float sd = stats[(b * G + g) * 3 + 1];
     // S1 was accumulated with scale = k/(sd+eps); the formula needs sum(k*du*x) = S1*(sd+eps)
