@@ -1,6 +1,6 @@
 """Time every (1,1) conv call of one UNet evaluation (fwd + VJP) stand-alone, with the call's own arguments."""
 import sys, os, torch, collections, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 from babe_amd import ops
 from babe_amd.networks import unet_engine
