@@ -1,0 +1,20 @@
+"""Duration of the single-workgroup projected-gradient filter fit (babe_filter_fit) on synthetic statistics."""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from babe_amd.stft import STFTOps, make_fit_cfg
+dev = torch.device("cuda", 0)
+st = STFTOps(4096, 368368, 44100, dev)
+g = torch.Generator().manual_seed(0)
+x = torch.randn(1, 368368, generator=g).to(dev)
+H = st.design_filter(torch.tensor([[3000.0], [-30.0]], device=dev))
+y = st.apply_filter(x, H)
+stats = st.mag_stats(st.stft(x), st.stft(y))
+cfg = make_fit_cfg(tol=(0.0, 0.0))          # never converges early: max_iter iterations
+p0 = torch.tensor([[[1000.0], [-20.0]]], device=dev)
+for _ in range(2):
+    p = p0.clone(); nit = st.filter_fit(stats, p, cfg)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+p = p0.clone()
+e0.record(); nit = st.filter_fit(stats, p, cfg); e1.record(); torch.cuda.synchronize()
+print(f"filter_fit: {e0.elapsed_time(e1)*1e3:.0f} us for {int(nit[0])} iterations -> fc={float(p[0,0,0]):.2f} Hz A={float(p[0,1,0]):.4f} dB")
