@@ -236,20 +236,6 @@ __global__ __launch_bounds__(256) void filter_fit_kernel(const double* __restric
     }
     int it = 0;
     const double cln = 0.11512925464970228;   // ln(10)/20
-    // The statistics and weights of this thread's bins do not change over the iterations: keep them in registers (the loop
-    // used to re-read 3 x nbins doubles from L2 in every iteration - a dependent-latency round trip per iteration of a
-    // single-workgroup kernel).  Bins beyond NBT * 256 (none for nfft = 4096) fall back to the loads.
-    constexpr int NBT = 9;
-    double cxx[NBT], cxy[NBT], cyy[NBT], cw2[NBT];
-#pragma unroll
-    for (int j = 0; j < NBT; ++j) {
-        const int k = threadIdx.x + j * 256;
-        const bool in = k < nbins;
-        cxx[j] = in ? Sxx[k] : 0.0;
-        cxy[j] = in ? Sxy[k] : 0.0;
-        cyy[j] = in ? Syy[k] : 0.0;
-        cw2[j] = in ? weight_sq(k, nbins, cfg.weighting) : 0.0;
-    }
     for (; it < cfg.max_iter; ++it) {
         __syncthreads();
         if (threadIdx.x == 0) build_filter(F, K, df, nbins);
@@ -257,17 +243,18 @@ __global__ __launch_bounds__(256) void filter_fit_kernel(const double* __restric
         double E[KMAX], Ep[KMAX], loss2 = 0;
 #pragma unroll
         for (int i = 0; i < KMAX; ++i) E[i] = Ep[i] = 0;
-        auto bin = [&](int k, double w2, double sxx, double sxy, double syy) {
+        for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
             const float f = (float)k * df;
             const int s = seg_of(F, K, f);
+            const double w2 = weight_sq(k, nbins, cfg.weighting);
             double Hk = 1.0, lg = 0.0;
             if (s >= 0) {
                 Hk = (double)(seg_val(f, F.fc[s], F.A[s]) * F.anchor[s]);
                 lg = (double)log2f(f / F.fc[s]);
             }
-            loss2 += w2 * (Hk * Hk * sxx - 2.0 * Hk * sxy + syy);
+            loss2 += w2 * (Hk * Hk * Sxx[k] - 2.0 * Hk * Sxy[k] + Syy[k]);
             if (s >= 0) {
-                const double e = w2 * (Hk * sxx - sxy) * Hk * cln;
+                const double e = w2 * (Hk * Sxx[k] - Sxy[k]) * Hk * cln;
 #pragma unroll
                 for (int i = 0; i < KMAX; ++i)
                     if (i == s) {
@@ -275,14 +262,7 @@ __global__ __launch_bounds__(256) void filter_fit_kernel(const double* __restric
                         Ep[i] += e * lg;
                     }
             }
-        };
-        // same bins in the same order as the original strided loop (k = tid, tid + 256, ...): identical sums
-#pragma unroll
-        for (int j = 0; j < NBT; ++j) {
-            const int k = threadIdx.x + j * 256;
-            if (k < nbins) bin(k, cw2[j], cxx[j], cxy[j], cyy[j]);
         }
-        for (int k = threadIdx.x + NBT * 256; k < nbins; k += 256) bin(k, weight_sq(k, nbins, cfg.weighting), Sxx[k], Sxy[k], Syy[k]);
         loss2 = wave_sum(loss2);
 #pragma unroll
         for (int i = 0; i < KMAX; ++i) {
