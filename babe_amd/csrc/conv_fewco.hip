@@ -15,7 +15,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-template <int CO>
+// CS = channel splits inside the workgroup: the 256 threads are 256/CS position quads x CS channel slices, partial sums
+// combined through LDS in a fixed order.  Small planes (the deep UNet levels: 7168 quads x 256 channels) otherwise fill 28
+// of 256 CUs with threads that each walk all 256 channels (189 us per launch; 42 us with CS = 8).
+template <int CO, int CS>
 __global__ __launch_bounds__(256) void conv_fewco_kernel(babe_conv_args a, const float* __restrict__ w, int tf) {
     extern __shared__ __attribute__((aligned(16))) float wl[];         // [ci][kh][co][4] (kw 0..2, pad)
     const int KH = a.KH;
@@ -35,11 +38,17 @@ __global__ __launch_bounds__(256) void conv_fewco_kernel(babe_conv_args a, const
         *reinterpret_cast<f32x4*>(wl + (long)i * 4) = f32x4{t0, t1, t2, 0.f};
     }
     __syncthreads();
+    constexpr int NQ = 256 / CS;
     const int q4 = a.T >> 2;
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const int pq = threadIdx.x % NQ, cs = threadIdx.x / NQ;
+    const long q = (long)blockIdx.x * NQ + pq;
     const int b = blockIdx.y;
-    if (q >= (long)a.F * q4) return;
-    const int f = (int)(q / q4), t = (int)(q % q4) * 4;
+    const bool live = q < (long)a.F * q4;
+    if (CS == 1 && !live) return;
+    const long qq = live ? q : 0;
+    const int f = (int)(qq / q4), t = (int)(qq % q4) * 4;
+    const int cpc = (a.Cin + CS - 1) / CS;                   // channels per slice
+    const int ci_lo = cs * cpc, ci_hi = ci_lo + cpc < a.Cin ? ci_lo + cpc : a.Cin;
     const int khc = KH >> 1;
     f32x4 acc[CO];
 #pragma unroll
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(256) void conv_fewco_kernel(babe_conv_args a, const
     }
     if (KH == 5) {
 #pragma unroll 2
-        for (int ci = 0; ci < a.Cin; ++ci) {
+        for (int ci = ci_lo; ci < ci_hi; ++ci) {
             const float* pc = xb + (long)ci * a.in_cs;
             const float* wc = wl + (long)ci * 5 * CO * 4;
             f32x4 v[5];
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_fewco_kernel(babe_conv_args a, const
             if (rmul[kh] == 0.f) continue;
             const float* xr = xb + roff[kh];
             const float* wk = wl + (long)kh * CO * 4;
-            for (int ci = 0; ci < a.Cin; ++ci) {
+            for (int ci = ci_lo; ci < ci_hi; ++ci) {
                 const float* p = xr + (long)ci * a.in_cs;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(p);
                 const float l = hl ? p[-1] : 0.f, r = hr ? p[4] : 0.f;
@@ -106,6 +115,19 @@ __global__ __launch_bounds__(256) void conv_fewco_kernel(babe_conv_args a, const
                 }
             }
         }
+    }
+    if (CS > 1) {                                            // combine the channel slices: slice 0 sums 1..CS-1 in order
+        __syncthreads();                                     // (all reads of the weight image are done: reuse its LDS)
+        f32x4* red = reinterpret_cast<f32x4*>(wl);
+        if (cs > 0) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c) red[((cs - 1) * NQ + pq) * CO + c] = acc[c];
+        }
+        __syncthreads();
+        if (cs > 0 || !live) return;
+        for (int s2 = 0; s2 < CS - 1; ++s2)
+#pragma unroll
+            for (int c = 0; c < CO; ++c) acc[c] += red[(s2 * NQ + pq) * CO + c];
     }
     const long sp = (long)f * a.T + t;
 #pragma unroll
@@ -142,18 +164,28 @@ extern "C" int babe_conv2d_fewco(const babe_conv_args* ap, const float* w, int t
     const double flops = babe_conv_flops(a);
     BabeProfScope prof(BABE_SLOT_CONV53_FEWCO, babe_conv_bytes(a), flops, 0, stream);
     const int co = a.Cout <= 2 ? 2 : 4;
-    const size_t lds = (size_t)a.Cin * a.KH * co * 16;
+    size_t lds = (size_t)a.Cin * a.KH * co * 16;
     const long nq = (long)a.F * (a.T / 4);
-    dim3 grid(cdiv(nq, 256), a.B);
-    if (co == 2) {
-        static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewco_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); once = true; }
-        hipLaunchKernelGGL(conv_fewco_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, a, w, transpose_flip);
-    } else {
-        static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewco_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); once = true; }
-        hipLaunchKernelGGL(conv_fewco_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a, w, transpose_flip);
+    // few position quads and many channels: split the channels inside the workgroup (8 slices) for 8x the workgroups
+    const bool split = nq * a.B < 256L * 1024 && a.Cin >= 64;
+    if (split && lds < (size_t)7 * 32 * co * 16) lds = (size_t)7 * 32 * co * 16;      // the reduction reuses the weight image
+#define FEWCO_LAUNCH(COv, CSv)                                                                                      \
+    {                                                                                                               \
+        static bool once = false;                                                                                   \
+        if (!once) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewco_kernel<COv, CSv>),                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);                      \
+            once = true;                                                                                            \
+        }                                                                                                           \
+        hipLaunchKernelGGL((conv_fewco_kernel<COv, CSv>), dim3(cdiv(nq, 256 / CSv), a.B), dim3(256), lds,           \
+                           (hipStream_t)stream, a, w, transpose_flip);                                              \
     }
+    if (co == 2) {
+        if (split) FEWCO_LAUNCH(2, 8) else FEWCO_LAUNCH(2, 1)
+    } else {
+        if (split) FEWCO_LAUNCH(4, 8) else FEWCO_LAUNCH(4, 1)
+    }
+#undef FEWCO_LAUNCH
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

@@ -1,7 +1,7 @@
 import sys, os, math, torch
 sys.path.insert(0, os.getcwd())
 from babe_amd import ops
-B=2
+B=int(os.environ.get("B","2"))
 Ns=[64,96,96,128,128,256,256]
 for i in range(7):
     F, T = 64*(i+1), (4096>>i) if i==6 else (4096>>i)//2
