@@ -72,7 +72,19 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     if (beg < end) {
         const long nv = (end - beg) / 4;
         const float4* p4 = reinterpret_cast<const float4*>(p + beg);
-        for (long i = threadIdx.x; i < nv; i += blockDim.x) {
+        // four independent 16-byte loads in flight per thread (one per iteration left the 512 workgroups of a launch at
+        // 3.9 TB/s: not enough bytes in flight per CU)
+        long i = threadIdx.x;
+        for (; i + 3 * (long)blockDim.x < nv; i += 4 * (long)blockDim.x) {
+            const float4 v0 = p4[i], v1 = p4[i + blockDim.x], v2 = p4[i + 2 * blockDim.x], v3 = p4[i + 3 * blockDim.x];
+            s0 += ((double)v0.x + (double)v0.y + (double)v0.z + (double)v0.w) + ((double)v1.x + (double)v1.y + (double)v1.z + (double)v1.w) +
+                  ((double)v2.x + (double)v2.y + (double)v2.z + (double)v2.w) + ((double)v3.x + (double)v3.y + (double)v3.z + (double)v3.w);
+            s1 += ((double)v0.x * v0.x + (double)v0.y * v0.y + (double)v0.z * v0.z + (double)v0.w * v0.w) +
+                  ((double)v1.x * v1.x + (double)v1.y * v1.y + (double)v1.z * v1.z + (double)v1.w * v1.w) +
+                  ((double)v2.x * v2.x + (double)v2.y * v2.y + (double)v2.z * v2.z + (double)v2.w * v2.w) +
+                  ((double)v3.x * v3.x + (double)v3.y * v3.y + (double)v3.z * v3.z + (double)v3.w * v3.w);
+        }
+        for (; i < nv; i += blockDim.x) {
             const float4 v = p4[i];
             s0 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
             s1 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
@@ -219,15 +231,25 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
             const long hi = end < (long)(cl + 1) * hw ? end : (long)(cl + 1) * hw;
             const float sc = scale[b * C + g * cg + cl];
             double sc_sum = 0;
-            for (long i = lo + (long)threadIdx.x * 4; i < hi; i += (long)blockDim.x * 4) {
-                const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
-                float4 dv = *reinterpret_cast<const float4*>(dadu + base + i);
+            auto term = [&](const float4 xv, float4 dv) {
                 dv.x *= gelu_grad_f(xv.x * sc);
                 dv.y *= gelu_grad_f(xv.y * sc);
                 dv.z *= gelu_grad_f(xv.z * sc);
                 dv.w *= gelu_grad_f(xv.w * sc);
-                sc_sum += (double)dv.x * xv.x + (double)dv.y * xv.y + (double)dv.z * xv.z + (double)dv.w * xv.w;
+                return (double)dv.x * xv.x + (double)dv.y * xv.y + (double)dv.z * xv.z + (double)dv.w * xv.w;
+            };
+            const long st = (long)blockDim.x * 4;
+            long i = lo + (long)threadIdx.x * 4;
+            for (; i + st < hi; i += 2 * st) {           // two iterations' loads (4 x 16 bytes) in flight per thread
+                const float4 x0 = *reinterpret_cast<const float4*>(x + base + i);
+                const float4 d0 = *reinterpret_cast<const float4*>(dadu + base + i);
+                const float4 x1 = *reinterpret_cast<const float4*>(x + base + i + st);
+                const float4 d1 = *reinterpret_cast<const float4*>(dadu + base + i + st);
+                sc_sum += term(x0, d0);
+                sc_sum += term(x1, d1);
             }
+            for (; i < hi; i += st)
+                sc_sum += term(*reinterpret_cast<const float4*>(x + base + i), *reinterpret_cast<const float4*>(dadu + base + i));
             s0 += (double)sc * sc_sum;
         }
     }
