@@ -33,6 +33,77 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// Alternative guidance distances of get_rec_grads (testing/blind_bwe_sampler.py:99-103).  r = y - rec is what the
+// filter / overlap-add kernels hand over; rec = y - r.
+// cosine: partial sums (rec.rec, rec.y, y.y) per block
+__global__ __launch_bounds__(256) void cos_partial_kernel(const float* __restrict__ r, long r_bs,
+                                                          const float* __restrict__ y, long y_bs,
+                                                          double* __restrict__ part, int nblk, long n) {
+    __shared__ double sh[4][3];
+    const int b = blockIdx.y;
+    const float* pr = r + (long)b * r_bs;
+    const float* py = y + (long)b * y_bs;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double yv = py[i], rc = yv - (double)pr[i];
+        a0 += rc * rc;
+        a1 += rc * yv;
+        a2 += yv * yv;
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6][0] = a0;
+        sh[threadIdx.x >> 6][1] = a1;
+        sh[threadIdx.x >> 6][2] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        part[((long)b * nblk + blockIdx.x) * 3 + threadIdx.x] =
+            sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// seed = d(distance)/d(rec) [* post]:  mode 1 smooth-L1 (sum reduction): -clamp(r / beta, -1, 1);
+// mode 2 cosine, distance = clamp(1 - cos(rec, y), min 0): -(y / (|rec||y|) - cos * rec / |rec|^2) where 1 - cos >= 0
+__global__ __launch_bounds__(256) void alt_seed_kernel(const float* __restrict__ r, long r_bs,
+                                                       const float* __restrict__ y, long y_bs,
+                                                       const double* __restrict__ part, int nblk,
+                                                       const float* __restrict__ post, float* __restrict__ out,
+                                                       long out_bs, int L, int mode, float beta) {
+    const int b = blockIdx.y;
+    float ca = 0.f, cb = 0.f;
+    if (mode == 2) {
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int i = 0; i < nblk; ++i) {
+            s0 += part[((long)b * nblk + i) * 3];
+            s1 += part[((long)b * nblk + i) * 3 + 1];
+            s2 += part[((long)b * nblk + i) * 3 + 2];
+        }
+        const double den = sqrt(s0) * sqrt(s2);
+        if (den > 0) {
+            const double c = s1 / den;
+            if (1.0 - c >= 0.0) {
+                ca = (float)(1.0 / den);
+                cb = (float)(c / s0);
+            }
+        }
+    }
+    const float ib = 1.f / beta;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long)gridDim.x * blockDim.x) {
+        const float rv = r[(long)b * r_bs + i];
+        float v;
+        if (mode == 1) {
+            v = -fminf(fmaxf(rv * ib, -1.f), 1.f);
+        } else {
+            const float yv = y[(long)b * y_bs + i];
+            v = -(yv * ca - (yv - rv) * cb);
+        }
+        if (post) v *= post[i];
+        out[(long)b * out_bs + i] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void score_direction_kernel(const float* __restrict__ xden,
                                                               const float* __restrict__ xhat,
                                                               const float* __restrict__ g,
@@ -143,6 +214,29 @@ extern "C" int babe_sumsq_partial(const float* g, long g_bs, double* part, int n
     BABE_CHECK_ARG(g && part && nblk > 0 && B > 0 && n > 0, "sumsq_partial: bad arguments");
     BabeProfScope prof(BABE_SLOT_SAMPLER, 4.0 * B * (double)n, 0, 0, stream);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, g, g_bs, part, nblk, n);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_cos_partial(const float* r, long r_bs, const float* y, long y_bs, double* part, int nblk, int B,
+                                long n, void* stream) {
+    BABE_CHECK_ARG(r && y && part && nblk > 0 && B > 0 && n > 0, "cos_partial: bad arguments");
+    BabeProfScope prof(BABE_SLOT_SAMPLER, 8.0 * B * (double)n, 0, 0, stream);
+    hipLaunchKernelGGL(cos_partial_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, r, r_bs, y, y_bs, part, nblk, n);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_residual_seed_alt(const float* r, long r_bs, const float* y, long y_bs, const double* part, int nblk,
+                                      const float* post, float* out, long out_bs, int B, int L, int mode, float beta,
+                                      void* stream) {
+    BABE_CHECK_ARG(r && out && B > 0 && L > 0 && (mode == 1 || mode == 2), "residual_seed_alt: bad arguments");
+    BABE_CHECK_ARG(mode == 1 ? beta > 0.f : (y && part && nblk > 0), "residual_seed_alt: mode %d needs %s", mode,
+                   mode == 1 ? "beta > 0" : "y and the cos_partial sums");
+    BabeProfScope prof(BABE_SLOT_SAMPLER, 12.0 * B * (double)L, 0, 0, stream);
+    int bx = cdiv(L, 1024);
+    hipLaunchKernelGGL(alt_seed_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, r, r_bs, y, y_bs, part, nblk, post,
+                       out, out_bs, L, mode, beta);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

@@ -41,6 +41,8 @@ def _register():
         "babe_filter_fit": [P, P, P, I, I, I, F, I, C.POINTER(FitCfg), P],
         "babe_lincomb3": [P, F, P, F, P, F, P, Lg, P],
         "babe_sumsq_partial": [P, Lg, P, I, I, Lg, P],
+        "babe_cos_partial": [P, Lg, P, Lg, P, I, I, Lg, P],
+        "babe_residual_seed_alt": [P, Lg, P, Lg, P, I, P, P, Lg, I, I, I, F, P],
         "babe_score_direction": [P, P, P, P, I, P, F, F, F, I, I, I, Lg, P],
         "babe_fir_same": [P, Lg, P, I, P, Lg, I, I, I, P],
         "babe_mask_blend": [P, P, Lg, P, P, I, Lg, P],
@@ -131,9 +133,24 @@ class STFTOps:
                              ptr(out), out.stride(0), ptr(part), self.NBLK, B, self.L, self.nfft, self.frames, stream()), "ola")
         return (out, part) if y is not None else out
 
-    def residual_seed(self, r, part, post=True):
+    def residual_seed(self, r, part, post=True, norm=2, y=None, beta=1.0):
+        """d(distance(y, rec))/d(rec) from r = y - rec, times the overlap-add normalisation if post.
+        norm 2 (default): -r/||r|| with the partial sums `part` of ||r||^2; 'smoothl1' / 'cosine': the alternative
+        distances of get_rec_grads (testing/blind_bwe_sampler.py:99-103)."""
         B = r.shape[0]
         out = torch.empty_like(r)
+        if norm != 2:
+            mode = {"smoothl1": 1, "cosine": 2}[norm]
+            cpart = None
+            if mode == 2:
+                assert y is not None and y.shape == r.shape
+                cpart = torch.empty(B, self.NBLK, 3, device=self.dev, dtype=torch.float64)
+                check(lib().babe_cos_partial(ptr(r), r.stride(0), ptr(y), y.stride(0), ptr(cpart), self.NBLK, B, r.shape[1],
+                                             stream()), "cos_partial")
+            check(lib().babe_residual_seed_alt(ptr(r), r.stride(0), ptr(y), y.stride(0) if y is not None else 0, ptr(cpart),
+                                               self.NBLK, ptr(self.env_inv) if post else None, ptr(out), out.stride(0), B,
+                                               r.shape[1], mode, float(beta), stream()), "residual_seed_alt")
+            return out
         check(lib().babe_residual_seed(ptr(r), r.stride(0), ptr(part), self.NBLK, ptr(self.env_inv) if post else None, ptr(out),
                                        out.stride(0), B, self.L, stream()), "residual_seed")
         return out

@@ -53,8 +53,11 @@ class BlindSampler:
         self.Amin, self.Amax = bb.Amin, bb.Amax
         self.tol = bb.optimization.tol
         self.start_sigma = None if ps.start_sigma == "None" else ps.start_sigma
-        if ps.norm != 2 or ps.stft_distance.use:
-            raise NotImplementedError("only posterior_sampling.norm=2 (the default of every blind-BWE config)")
+        if ps.norm not in (2, "smoothl1", "cosine") or ps.stft_distance.use:
+            raise NotImplementedError("posterior_sampling.norm must be 2, 'smoothl1' or 'cosine' (the STFT-domain distances "
+                                      "of conf/tester/blind_bwe_2.yaml / blind_bwe_with_prior.yaml are not built)")
+        self.norm = ps.norm
+        self.smoothl1_beta = ps.get("smoothl1_beta", 1.0)
         if ps.SNR_observations != "None" or bb.get("sigma_den_estimate", 0):
             raise NotImplementedError("observation-noise regularisation (SNR_observations / sigma_den_estimate)")
         if self.data_consistency:
@@ -93,6 +96,10 @@ class BlindSampler:
         part = torch.empty(B, self.NBLK, device=g.device, dtype=torch.float64)
         check(lib().babe_sumsq_partial(ptr(g), g.stride(0), ptr(part), self.NBLK, B, n, stream()), "sumsq_partial")
         return part
+
+    def _seed(self, st, r, y, part, post):
+        """d(distance)/d(rec) for the configured guidance distance (get_rec_grads :99-117)."""
+        return st.residual_seed(r, part, post=post, norm=self.norm, y=y, beta=self.smoothl1_beta)
 
     def _lane_kw(self, lane):
         return {"lane": lane} if (lane is not None and getattr(self.model, "supports_lanes", False)) else {}
@@ -144,18 +151,18 @@ class BlindSampler:
             rec = mask_blend(m, x_den, rec0)
             r = lincomb(torch.empty_like(y), 1.0, y, -1.0, rec)
             part = self._sumsq(r)
-            seed_raw = st.residual_seed(r, part, post=False)                 # -r/||r||
+            seed_raw = self._seed(st, r, y, part, post=False)                # -r/||r||
             if self.fir_taps is not None:
                 gA = fir_same(mask_blend(m, None, seed_raw), self.fir_taps, adjoint=True)
             else:
-                u = mask_blend(m, None, st.residual_seed(r, part, post=True))
+                u = mask_blend(m, None, self._seed(st, r, y, part, post=True))
                 gA = st.ola(st.filter_frames(st.stft(u), Hq), normalise=False)
             g_den = lincomb(torch.empty_like(gA), 1.0, mask_blend(m, seed_raw, None), 1.0, gA)
         elif self.fir_taps is not None:
             # known FIR degradation (edm_sampler.py:245-252): residual, then the transpose FIR
             rec = fir_same(x_den, self.fir_taps)
             r = lincomb(torch.empty_like(y), 1.0, y, -1.0, rec)
-            seed = st.residual_seed(r, self._sumsq(r), post=False)
+            seed = self._seed(st, r, y, self._sumsq(r), post=False)
             g_den = fir_same(seed, self.fir_taps, adjoint=True)
         else:
             specX = st.stft(x_den)
@@ -165,7 +172,7 @@ class BlindSampler:
             Hq = H if H.shape[0] == B else H[0]
             # reconstruction guidance: forward residual and hand-wired VJP
             r, part = st.ola(st.filter_frames(specX, Hq), normalise=True, y=y)
-            seed = st.residual_seed(r, part)
+            seed = self._seed(st, r, y, part, post=True)
             g_den = st.ola(st.filter_frames(st.stft(seed), Hq), normalise=False)
         if self.args.tester.filter_out_cqt_DC_Nyq:
             g_den = cq.apply_hpf_DC(g_den)                      # zero-phase real filter: self-adjoint

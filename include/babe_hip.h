@@ -231,6 +231,14 @@ int babe_mask_blend(float* out, const float* mask, long mask_bs, const float* a,
                     void* stream);
 /* part[b][blk] = sum of squares of g[b][blk-th slice] (double) */
 int babe_sumsq_partial(const float* g, long g_bs, double* part, int nblk, int B, long n, void* stream);
+/* Alternative guidance distances of get_rec_grads (testing/blind_bwe_sampler.py:99-103; conf/tester/blind_bwe_cossim.yaml):
+ * seed = d(distance)/d(rec) [* post] from r = y - rec.  mode 1: smooth_l1_loss(y, rec, reduction='sum', beta):
+ * -clamp(r / beta, -1, 1).  mode 2: clamp(1 - CosineSimilarity(rec, y), min 0) per batch item, with the three sums
+ * (rec.rec, rec.y, y.y) from babe_cos_partial (part: [B][nblk][3] doubles). */
+int babe_cos_partial(const float* r, long r_bs, const float* y, long y_bs, double* part, int nblk, int B, long n,
+                     void* stream);
+int babe_residual_seed_alt(const float* r, long r_bs, const float* y, long y_bs, const double* part, int nblk,
+                           const float* post, float* out, long out_bs, int B, int L, int mode, float beta, void* stream);
 /* mode 0 (blind_bwe_sampler.py:125-135,701): d = -t*((xden-xhat)/t^2 - s*g/t), s = xi/(||g||/sqrt(audio_len) + 1e-6)
  * mode 1 (edm_sampler.py:78-92):              d = -t*((xden-xhat)/t^2 - s*g),   s = xi/(||g||/sqrt(audio_len)*t + 1e-6)
  * shared_norm=1 uses the norm over the whole batch (reference semantics). */

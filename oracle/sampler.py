@@ -2,7 +2,7 @@
 
 Follows /root/reference/testing/blind_bwe_sampler.py: predict_blind_bwe
 :619-769, move_timestep :509-516, get_denoised_estimate :152-157,
-get_rec_grads :75-135 (norm: 2 path), fit_params :533-595, and the known-filter
+get_rec_grads :75-135 (norm: 2, 'smoothl1' :99-100 and 'cosine' :101-103), fit_params :533-595, and the known-filter
 variant predict_bwe('fc_A') :351-364 + predict :406-498.
 Noise is injected (list of tensors in the reference's draw order: prior first,
 then one per step) so runs are reproducible against the golden records (G8).
@@ -17,8 +17,9 @@ class OracleBlindSampler:
     def __init__(self, net, cqt, edm_params, *, fs, audio_len, T=35, order=2, xi=0.2, start_sigma=0.2,
                  nfft=4096, fc_init=(280, 285, 290, 295, 300), A_init=(-15, -17, -20, -25, -30),
                  mu=(1000.0, 10.0), tol=(5e-3, 5e-3), max_iter=100, fcmin=20.0, Amin=-50.0,
-                 weighting="sqrt", filter_out_cqt_DC_Nyq=True):
+                 weighting="sqrt", filter_out_cqt_DC_Nyq=True, norm=2, smoothl1_beta=1.0):
         self.net, self.cqt, self.p = net, cqt, edm_params
+        self.norm, self.smoothl1_beta = norm, smoothl1_beta
         self.fs, self.audio_len, self.T, self.order, self.xi = fs, audio_len, T, order, xi
         self.start_sigma, self.nfft = start_sigma, nfft
         self.fc_init, self.A_init = fc_init, A_init
@@ -26,6 +27,14 @@ class OracleBlindSampler:
                            weighting=weighting)
         self.hpf = filter_out_cqt_DC_Nyq
         self.freqs = U.bin_freqs(nfft, fs)
+
+    def distance(self, y, rec):
+        """posterior_sampling.norm of get_rec_grads (:99-117), per batch item (smooth-L1: one scalar, 'sum' reduction)."""
+        if self.norm == "smoothl1":
+            return torch.nn.functional.smooth_l1_loss(y, rec, reduction="sum", beta=self.smoothl1_beta)
+        if self.norm == "cosine":
+            return (1 - torch.nn.functional.cosine_similarity(rec, y, dim=1, eps=1e-6)).clamp(min=0)
+        return torch.linalg.norm(y - rec, dim=1, ord=self.norm)
 
     def denoised(self, x, t):
         xd = E.denoiser(self.p, self.net, x, t.reshape(1, 1).expand(x.shape[0], 1) if t.dim() == 0 else t)
@@ -36,7 +45,7 @@ class OracleBlindSampler:
     def rec_grads(self, x_den, y, x, t, params):
         H = U.design_filter(params[0], params[1], self.freqs)
         rec = U.apply_filter(x_den, H, self.nfft)
-        norm = torch.linalg.norm(y - rec, dim=1, ord=2)
+        norm = self.distance(y, rec)
         g, = torch.autograd.grad(norm.sum(), x)
         s = self.xi / (torch.linalg.norm(g) / self.audio_len ** 0.5 + 1e-6)
         return s * g / t
@@ -61,7 +70,7 @@ class OracleBlindSampler:
         else:
             H = U.design_filter(params[0], params[1], self.freqs)
             rec = U.apply_filter(x_den, H, self.nfft)
-            norm = torch.linalg.norm(y - rec, dim=1, ord=2)
+            norm = self.distance(y, rec)
             t3 = tick()
             g, = torch.autograd.grad(norm.sum(), x)
             t4 = tick()

@@ -705,7 +705,61 @@ def g15():
     save("complete_recording.npz", **out)
 
 
+# ---------------------------------------------------------------- G16: alternative guidance distances (get_rec_grads :99-103)
+def g16():
+    """T=3 blind sampler runs with posterior_sampling.norm = 'cosine' (conf/tester/blind_bwe_cossim.yaml) and 'smoothl1'
+    (beta = smoothl1_beta); same network wrapper, observation and recorded noises as g7_8's sampler_small."""
+    out = {}
+    for norm in ("cosine", "smoothl1"):
+        args = small_args(T=3)
+        net, sd = build_ref_net(args)
+        L = args.exp.audio_len                                     # (the weights are those of unet_small.npz: same seed)
+
+        class ResidualNet:
+            def __init__(self, inner, a, sigma_data):
+                self.inner, self.a, self.sd = inner, a, sigma_data
+                self.CQTransform = inner.CQTransform
+
+            def __call__(self, x, cnoise):
+                return self.a * self.inner(x, cnoise) + (torch.exp(4 * cnoise) / self.sd) * x
+
+        args.tester.posterior_sampling.start_sigma = 0.05
+        args.tester.posterior_sampling.norm = norm
+        args.tester.posterior_sampling.smoothl1_beta = 0.01       # |y - rec| straddles beta: both branches are exercised
+        args.tester.blind_bwe.optimization.mu = [100, 1]          # a contractive fit (as g13's B=2 golden): see DESIGN 4
+        e = edm_mod.EDM(args)
+        with quiet():
+            s = samp_mod.BlindSampler(ResidualNet(net, 0.3, args.tester.diff_params.sigma_data), e, args)
+        g = torch.Generator().manual_seed(4242)
+        t_ax = torch.arange(L) / args.exp.sample_rate
+        clean = sum(0.05 / (k + 1) * torch.sin(2 * np.pi * 220.0 * (k + 1) * t_ax) * torch.exp(-t_ax * (1 + k)) for k in range(12))
+        clean = clean[None] + 0.1 * torch.randn(1, L, generator=g)
+        f = torch.fft.rfftfreq(4096, d=1 / args.exp.sample_rate)
+        Ht = bu.design_filter(torch.tensor([2000.0]), torch.tensor([-40.0]), f)
+        y = bu.apply_filter(clean, Ht, 4096)
+        noises = [torch.randn(1, L, generator=g) for _ in range(1 + args.tester.T)]
+        it = iter(noises)
+        orig_randn = torch.randn
+        torch.randn = lambda *a, **k: next(it)
+        try:
+            with quiet(), contextlib.redirect_stderr(io.StringIO()):
+                xres, fp, data_den, t, data_filt = s.predict_blind_bwe(y.clone(), rid=True)
+        finally:
+            torch.randn = orig_randn
+        out.update({"seed": 4242, "res_a": 0.3, "start_sigma": 0.05, "smoothl1_beta": 0.01, "mu": [100.0, 1.0], "y": y, f"x_{norm}": xres,
+                    f"filter_params_{norm}": fp, f"data_filters_{norm}": data_filt})
+        # a single guidance term at a fixed point: rec_grads of get_rec_grads for the unit test of the seed kernels
+        x0 = (0.05 * torch.randn(1, L, generator=g)).requires_grad_(True)
+        with quiet():
+            xd = s.get_denoised_estimate(x0, torch.tensor(0.04))
+            rg = s.get_rec_grads(xd, y, x0, torch.tensor(0.04),
+                                 lambda xx, fp_: bu.apply_filter(xx, bu.design_filter(fp_[0], fp_[1], f), 4096),
+                                 torch.tensor([[2000.0], [-40.0]]))
+        out.update({f"rg_x0_{norm}": x0.detach(), f"rg_{norm}": rg.detach()})
+    save("sampler_altnorm.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     for w in which:
         globals()[w]()

@@ -457,3 +457,28 @@ def test_clip_lanes_equal_single_stream_loop():
     smp._randn = lambda shape, device: next(it).to(device)
     x1, fp1 = smp.predict_blind_bwe(y[2:3].cuda())
     assert torch.equal(outs[0][0][2:3], x1) and torch.equal(outs[0][1][2], fp1)
+
+
+@pytest.mark.parametrize("norm", ["cosine", "smoothl1"])
+def test_blind_sampler_alternative_guidance_distances(norm):
+    """posterior_sampling.norm = 'cosine' / 'smoothl1' (get_rec_grads :99-103) on the HIP path (babe_cos_partial,
+    babe_residual_seed_alt): T=3 blind run against the imported reference (G16)."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    s = load("sampler_altnorm.npz")
+    g, args, net = small_net(T=3, start_sigma=float(s["start_sigma"]))
+    args.tester.posterior_sampling.norm = norm
+    args.tester.posterior_sampling.smoothl1_beta = float(s["smoothl1_beta"])
+    args.tester.blind_bwe.optimization.mu = [float(v) for v in s["mu"]]
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    smp = BlindSampler(ResidualNet(net, float(s["res_a"]), 0.063), EDM(args), args)
+    it = iter(noises)
+    smp._randn = lambda shape, device: next(it).to(device)
+    x, fp, dden, t, dfil = smp.predict_blind_bwe(s["y"].cuda(), rid=True)
+    for i in range(3):
+        assert params_close(dfil[i], s[f"data_filters_{norm}"][i]), (i, dfil[i], s[f"data_filters_{norm}"][i])
+    assert rms_err(x, s[f"x_{norm}"]) < 1e-3 and rel(x, s[f"x_{norm}"]) < 2e-3
+    assert params_close(fp, s[f"filter_params_{norm}"])

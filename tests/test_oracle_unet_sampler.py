@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import edm as E
@@ -201,3 +202,28 @@ def test_sampler_B2_reference_batch_semantics():
         assert rel(rec[i]["x_den"][:, ::16], s["data_denoised_sub16"][i]) < 1e-3, i
         assert params_close(rec[i]["params"], s["data_filters"][i]), i
     assert rel(x, s["x"]) < 1e-3 and params_close(fp, s["filter_params"])
+
+
+@pytest.mark.parametrize("norm", ["cosine", "smoothl1"])
+def test_sampler_alternative_guidance_distances(norm):
+    """posterior_sampling.norm = 'cosine' (conf/tester/blind_bwe_cossim.yaml) / 'smoothl1' (get_rec_grads :99-103): the
+    oracle's single guidance term and its T=3 blind run against the imported reference (G16)."""
+    g, sd, cqt = small_net()
+    s = load("sampler_altnorm.npz")
+    L = 92092
+    a = float(s["res_a"])
+    p = E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10, Stmin=0, Stmax=50, Snoise=1.0)
+    net = lambda x, cn: a * UN.unet_forward(sd, CFG, cqt, x, cn) + (torch.exp(4 * cn) / 0.063) * x
+    smp = OracleBlindSampler(net, cqt, p, fs=22050, audio_len=L, T=3, start_sigma=float(s["start_sigma"]), norm=norm,
+                             smoothl1_beta=float(s["smoothl1_beta"]), mu=tuple(float(v) for v in s["mu"]))
+    x0 = s[f"rg_x0_{norm}"].clone().requires_grad_(True)
+    rg = smp.rec_grads(smp.denoised(x0, torch.tensor(0.04)), s["y"], x0, torch.tensor(0.04), torch.tensor([[2000.0], [-40.0]]))
+    assert rel(rg, s[f"rg_{norm}"]) < 1e-4
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    rec = []
+    x, fp = smp.predict_blind_bwe(s["y"], noises, record=rec)
+    for i in range(3):
+        assert params_close(rec[i]["params"], s[f"data_filters_{norm}"][i]), i
+    assert rel(x, s[f"x_{norm}"]) < 1e-3 and params_close(fp, s[f"filter_params_{norm}"])
