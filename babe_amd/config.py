@@ -49,7 +49,7 @@ def default_args(sample_rate=44100, audio_len=368368, Ns=(64, 96, 96, 128, 128, 
             T=T, order=2, filter_out_cqt_DC_Nyq=True,
             posterior_sampling=dict(xi=xi, data_consistency=False, norm=2, smoothl1_beta=1, SNR_observations="None",
                                     start_sigma=start_sigma, freq_weighting="None", freq_weighting_filter="sqrt",
-                                    stft_distance=dict(mag=False, use=False, use_multires=False, nfft=2048)),
+                                    stft_distance=dict(mag=False, logmag=False, use=False, use_multires=False, nfft=2048)),
             diff_params=dict(same_as_training=False, sigma_data=0.063, sigma_min=1e-4, sigma_max=1, ro=8, Schurn=10,
                              Snoise=1.0, Stmin=0, Stmax=50),
             blind_bwe=dict(NFFT=4096, fcmin=20, fcmax="nyquist", Amin=-50, Amax=30, sigma_den_estimate=0.0,

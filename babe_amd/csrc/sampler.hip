@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void alt_seed_kernel(const float* __restrict__
         float v;
         if (mode == 1) {
             v = -fminf(fmaxf(rv * ib, -1.f), 1.f);
+        } else if (mode == 3) {
+            v = rv;                                    // r already IS d(distance)/d(rec) (STFT-domain distances): only * post
         } else {
             const float yv = y[(long)b * y_bs + i];
             v = -(yv * ca - (yv - rv) * cb);
@@ -230,9 +232,9 @@ extern "C" int babe_cos_partial(const float* r, long r_bs, const float* y, long 
 extern "C" int babe_residual_seed_alt(const float* r, long r_bs, const float* y, long y_bs, const double* part, int nblk,
                                       const float* post, float* out, long out_bs, int B, int L, int mode, float beta,
                                       void* stream) {
-    BABE_CHECK_ARG(r && out && B > 0 && L > 0 && (mode == 1 || mode == 2), "residual_seed_alt: bad arguments");
-    BABE_CHECK_ARG(mode == 1 ? beta > 0.f : (y && part && nblk > 0), "residual_seed_alt: mode %d needs %s", mode,
-                   mode == 1 ? "beta > 0" : "y and the cos_partial sums");
+    BABE_CHECK_ARG(r && out && B > 0 && L > 0 && mode >= 1 && mode <= 3, "residual_seed_alt: bad arguments");
+    BABE_CHECK_ARG(mode != 1 || beta > 0.f, "residual_seed_alt: mode 1 needs beta > 0");
+    BABE_CHECK_ARG(mode != 2 || (y && part && nblk > 0), "residual_seed_alt: mode 2 needs y and the cos_partial sums");
     BabeProfScope prof(BABE_SLOT_SAMPLER, 12.0 * B * (double)L, 0, 0, stream);
     int bx = cdiv(L, 1024);
     hipLaunchKernelGGL(alt_seed_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, r, r_bs, y, y_bs, part, nblk, post,

@@ -110,6 +110,73 @@ __global__ __launch_bounds__(256) void residual_seed_kernel(const float* __restr
     }
 }
 
+// STFT-domain guidance distances (get_rec_grads :105-115 -> utils/blind_bwe_utils.py:148-247): X = S(rec), R = S(y), both
+// [B][frames][nbins] complex, w[nbins] the frequency weighting.  mode 0: D = ||w (X - R)||_2 (apply_norm_STFT_fweighted),
+// 1: ||w|X| - w|R|||_2, 2: ||log10(w|X| + 1e-8) - log10(w|R| + 1e-8)||_2 (apply_norm_STFTmag_fweighted).
+__device__ __forceinline__ float stft_dist_term(float2 x, float2 r, float w, int mode, float& mx) {
+    if (mode == 0) {
+        const float dr = w * x.x - w * r.x, di = w * x.y - w * r.y;
+        mx = 0.f;
+        return dr * dr + di * di;
+    }
+    mx = sqrtf(x.x * x.x + x.y * x.y);
+    const float mr = sqrtf(r.x * r.x + r.y * r.y);
+    const float d = mode == 1 ? mx * w - mr * w : log10f(mx * w + 1e-8f) - log10f(mr * w + 1e-8f);
+    return d * d;
+}
+// grid (nblk, B): partial sums of the squared terms
+__global__ __launch_bounds__(256) void stft_dist_partial_kernel(const float* __restrict__ X, const float* __restrict__ R,
+                                                                const float* __restrict__ w, double* __restrict__ part,
+                                                                int nblk, int nbins, long n, int mode) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    const float2* x2 = reinterpret_cast<const float2*>(X) + (long)b * n;
+    const float2* r2 = reinterpret_cast<const float2*>(R) + (long)b * n;
+    double acc = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float mx;
+        acc += (double)stft_dist_term(x2[i], r2[i], w[i % nbins], mode, mx);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// G = dD/dX (real, imag); shared: one D over the whole batch (the reference's coupling), else one per batch item
+__global__ __launch_bounds__(256) void stft_dist_grad_kernel(const float* __restrict__ X, const float* __restrict__ R,
+                                                             const float* __restrict__ w, const double* __restrict__ part,
+                                                             int nblk, float* __restrict__ G, int nbins, long n, int mode,
+                                                             int shared, int B) {
+    const int b = blockIdx.y;
+    double s = 0;
+    const int b0 = shared ? 0 : b, b1 = shared ? B : b + 1;
+    for (int bb = b0; bb < b1; ++bb)
+        for (int i = 0; i < nblk; ++i) s += part[(long)bb * nblk + i];
+    const float invD = s > 0 ? (float)(1.0 / sqrt(s)) : 0.f;
+    const float2* x2 = reinterpret_cast<const float2*>(X) + (long)b * n;
+    const float2* r2 = reinterpret_cast<const float2*>(R) + (long)b * n;
+    float2* g2 = reinterpret_cast<float2*>(G) + (long)b * n;
+    const float iln10 = 0.43429448190325176f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float2 x = x2[i], r = r2[i];
+        const float ww = w[i % nbins];
+        float2 g;
+        if (mode == 0) {
+            g.x = ww * (ww * x.x - ww * r.x) * invD;
+            g.y = ww * (ww * x.y - ww * r.y) * invD;
+        } else {
+            const float mx = sqrtf(x.x * x.x + x.y * x.y), mr = sqrtf(r.x * r.x + r.y * r.y);
+            float c;                                   // dD/d|X|
+            if (mode == 1) c = (mx * ww - mr * ww) * invD * ww;
+            else c = (log10f(mx * ww + 1e-8f) - log10f(mr * ww + 1e-8f)) * invD * iln10 / (mx * ww + 1e-8f) * ww;
+            const float im = mx > 0.f ? 1.f / mx : 0.f;
+            g.x = c * x.x * im;
+            g.y = c * x.y * im;
+        }
+        g2[i] = g;
+    }
+}
+
 // grid (ceil(nbins/256), Bout): threads over bins, loop over frames (and batch if shared)
 __global__ __launch_bounds__(256) void mag_stats_kernel(const float* __restrict__ sx, const float* __restrict__ sy,
                                                         double* __restrict__ stats, int B, int nbins, int frames,
@@ -395,6 +462,29 @@ extern "C" int babe_residual_seed(const float* r, long r_bs, const double* part,
     int bx = cdiv(L, 1024);
     hipLaunchKernelGGL(residual_seed_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, r, r_bs, part, nblk, post,
                        out, out_bs, L);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_stft_dist_partial(const float* X, const float* R, const float* w, double* part, int nblk, int B,
+                                      int nbins, int frames, int mode, void* stream) {
+    BABE_CHECK_ARG(X && R && w && part && nblk > 0 && B > 0 && nbins > 1 && frames > 0 && mode >= 0 && mode <= 2,
+                   "stft_dist_partial: bad arguments");
+    BabeProfScope prof(BABE_SLOT_SAMPLER, 16.0 * B * (double)nbins * frames, 0, 0, stream);
+    hipLaunchKernelGGL(stft_dist_partial_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, X, R, w, part, nblk, nbins,
+                       (long)nbins * frames, mode);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_stft_dist_grad(const float* X, const float* R, const float* w, const double* part, int nblk, float* G,
+                                   int B, int nbins, int frames, int mode, int shared, void* stream) {
+    BABE_CHECK_ARG(X && R && w && part && G && nblk > 0 && B > 0 && nbins > 1 && frames > 0 && mode >= 0 && mode <= 2,
+                   "stft_dist_grad: bad arguments");
+    BabeProfScope prof(BABE_SLOT_SAMPLER, 24.0 * B * (double)nbins * frames, 0, 0, stream);
+    const long n = (long)nbins * frames;
+    hipLaunchKernelGGL(stft_dist_grad_kernel, dim3(cdiv(n, 1024), B), dim3(256), 0, (hipStream_t)stream, X, R, w, part, nblk,
+                       G, nbins, n, mode, shared, B);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

@@ -42,6 +42,8 @@ def _register():
         "babe_lincomb3": [P, F, P, F, P, F, P, Lg, P],
         "babe_sumsq_partial": [P, Lg, P, I, I, Lg, P],
         "babe_cos_partial": [P, Lg, P, Lg, P, I, I, Lg, P],
+        "babe_stft_dist_partial": [P, P, P, P, I, I, I, I, I, P],
+        "babe_stft_dist_grad": [P, P, P, P, I, P, I, I, I, I, I, P],
         "babe_residual_seed_alt": [P, Lg, P, Lg, P, I, P, P, Lg, I, I, I, F, P],
         "babe_score_direction": [P, P, P, P, I, P, F, F, F, I, I, I, Lg, P],
         "babe_fir_same": [P, Lg, P, I, P, Lg, I, I, I, P],
@@ -82,6 +84,18 @@ def mask_blend(mask, a=None, b=None):
     mbs = 0 if mask.dim() == 1 or mask.shape[0] == 1 else mask.stride(0)
     check(lib().babe_mask_blend(ptr(out), ptr(mask.contiguous()), mbs, ptr(a), ptr(b), B, n, stream()), "mask_blend")
     return out
+
+
+def freq_weights(nbins, kind):
+    """Frequency weighting of the STFT-domain guidance distances (utils/blind_bwe_utils.py:159-196): w(f), f = linspace(0, 1)."""
+    fr = torch.linspace(0, 1, nbins, dtype=torch.float32)
+    table = {"None": lambda: torch.ones_like(fr), "linear": lambda: fr, "sqrt": lambda: torch.sqrt(fr),
+             "log": lambda: torch.log2(1 + fr), "quadratic": lambda: fr ** 2, "cubic": lambda: fr ** 3,
+             "squared": lambda: fr ** 4, "logquadratic": lambda: torch.log2(1 + fr ** 2),
+             "logcubic": lambda: torch.log2(1 + fr ** 3)}
+    if kind not in table:
+        raise NotImplementedError(f"freq_weighting={kind!r} (implemented: {sorted(table)}; 'log2' / 'log10' are -inf at DC)")
+    return table[kind]().contiguous()
 
 
 class STFTOps:
@@ -140,7 +154,7 @@ class STFTOps:
         B = r.shape[0]
         out = torch.empty_like(r)
         if norm != 2:
-            mode = {"smoothl1": 1, "cosine": 2}[norm]
+            mode = {"smoothl1": 1, "cosine": 2, "ready": 3}[norm]        # 'ready': r already is the gradient w.r.t. rec
             cpart = None
             if mode == 2:
                 assert y is not None and y.shape == r.shape
@@ -179,6 +193,24 @@ class STFTOps:
         check(lib().babe_filter_fit(ptr(stats), ptr(params), ptr(nit), P_, K, self.nbins, self.fs, self.nfft,
                                     C.byref(cfg), stream()), "filter_fit")
         return nit
+
+    def distance_grad(self, rec, y, weight, mode, shared=False):
+        """d D(y, rec) / d rec for the STFT-domain guidance distances (get_rec_grads :105-115): mode 0 complex, 1 magnitude,
+        2 log-magnitude (utils/blind_bwe_utils.py:148-247); weight [nbins].  STFT^T is the overlap-add of windowed inverse
+        FFTs of G * nfft * [1, 1/2, ..., 1/2, 1]."""
+        B = rec.shape[0]
+        X, R = self.stft(rec), self.stft(y)
+        part = torch.empty(B, self.NBLK, device=self.dev, dtype=torch.float64)
+        check(lib().babe_stft_dist_partial(ptr(X), ptr(R), ptr(weight), ptr(part), self.NBLK, B, self.nbins, self.frames, mode,
+                                           stream()), "stft_dist_partial")
+        G = torch.empty_like(X)
+        check(lib().babe_stft_dist_grad(ptr(X), ptr(R), ptr(weight), ptr(part), self.NBLK, ptr(G), B, self.nbins, self.frames,
+                                        mode, int(shared), stream()), "stft_dist_grad")
+        if getattr(self, "_Hadj", None) is None:
+            h = torch.full((self.nbins,), 0.5 * self.nfft, device=self.dev)
+            h[0] = h[-1] = float(self.nfft)
+            self._Hadj = h
+        return self.ola(self.filter_frames(G, self._Hadj), normalise=False)
 
     # -- composites
     def apply_filter(self, x, H):

@@ -53,10 +53,15 @@ class BlindSampler:
         self.Amin, self.Amax = bb.Amin, bb.Amax
         self.tol = bb.optimization.tol
         self.start_sigma = None if ps.start_sigma == "None" else ps.start_sigma
-        if ps.norm not in (2, "smoothl1", "cosine") or ps.stft_distance.use:
-            raise NotImplementedError("posterior_sampling.norm must be 2, 'smoothl1' or 'cosine' (the STFT-domain distances "
-                                      "of conf/tester/blind_bwe_2.yaml / blind_bwe_with_prior.yaml are not built)")
+        if ps.norm not in (2, "smoothl1", "cosine"):
+            raise NotImplementedError("posterior_sampling.norm must be 2, 'smoothl1' or 'cosine'")
         self.norm = ps.norm
+        self.stft_dist = None
+        if ps.norm == 2 and ps.stft_distance.use:          # same precedence as get_rec_grads :99-117
+            if ps.stft_distance.use_multires:
+                raise NotImplementedError("posterior_sampling.stft_distance.use_multires (auraloss multi-resolution loss)")
+            mode = (2 if ps.stft_distance.get("logmag", False) else 1) if ps.stft_distance.mag else 0
+            self.stft_dist = dict(nfft=int(ps.stft_distance.nfft), mode=mode, weight=ps.freq_weighting)
         self.smoothl1_beta = ps.get("smoothl1_beta", 1.0)
         if ps.SNR_observations != "None" or bb.get("sigma_den_estimate", 0):
             raise NotImplementedError("observation-noise regularisation (SNR_observations / sigma_den_estimate)")
@@ -99,6 +104,16 @@ class BlindSampler:
 
     def _seed(self, st, r, y, part, post):
         """d(distance)/d(rec) for the configured guidance distance (get_rec_grads :99-117)."""
+        if self.stft_dist is not None:
+            sd = self.stft_dist
+            if sd.get("ops") is None or sd["ops"].L != r.shape[1] or sd["ops"].dev != r.device:
+                from ..stft import STFTOps
+                from ..stft import freq_weights
+                sd["ops"] = STFTOps(sd["nfft"], r.shape[1], self.args.exp.sample_rate, r.device)
+                sd["w"] = freq_weights(sd["ops"].nbins, sd["weight"]).to(r.device)
+            rec = lincomb(torch.empty_like(r), 1.0, y, -1.0, r)             # r = y - rec
+            g = sd["ops"].distance_grad(rec, y, sd["w"], sd["mode"], shared=self.batch_semantics == "reference")
+            return st.residual_seed(g, None, post=post, norm="ready") if post else g
         return st.residual_seed(r, part, post=post, norm=self.norm, y=y, beta=self.smoothl1_beta)
 
     def _lane_kw(self, lane):

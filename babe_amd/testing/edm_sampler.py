@@ -36,7 +36,7 @@ class Sampler(BlindSampler):
         self.batch_semantics = batch_semantics
         self.noise_device = noise_device
         self._stft = None
-        self.norm, self.smoothl1_beta = 2, 1.0        # edm_sampler.py:71: torch.linalg.norm(y - den_rec, ord=2) only
+        self.norm, self.smoothl1_beta, self.stft_dist = 2, 1.0, None      # edm_sampler.py:71: torch.linalg.norm(y - den_rec, ord=2) only
         self.fir_taps = None
         self.ar_mask = None
         self.dc = None

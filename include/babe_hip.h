@@ -231,10 +231,20 @@ int babe_mask_blend(float* out, const float* mask, long mask_bs, const float* a,
                     void* stream);
 /* part[b][blk] = sum of squares of g[b][blk-th slice] (double) */
 int babe_sumsq_partial(const float* g, long g_bs, double* part, int nblk, int B, long n, void* stream);
+/* STFT-domain guidance distances (get_rec_grads :105-115 -> utils/blind_bwe_utils.py:148-247; conf/tester/blind_bwe_2.yaml):
+ * X = STFT(rec), R = STFT(y) as [B][frames][nbins] complex (babe_stft_fwd), w[nbins] = frequency weighting.  mode 0:
+ * ||w (X - R)||_2, 1: ||w|X| - w|R|||_2, 2: ||log10(w|X| + 1e-8) - log10(w|R| + 1e-8)||_2.  babe_stft_dist_partial writes
+ * partial sums of squares ([B][nblk] doubles), babe_stft_dist_grad G = dD/dX with ONE D over the batch (shared = 1, the
+ * reference) or per item; d/d(rec) = STFT^T(G) = babe_ola(babe_spec_filter_istft(G, H = nfft * [1, 1/2, ..., 1/2, 1])).
+ * babe_residual_seed_alt mode 3 multiplies such a ready gradient by the overlap-add normalisation. */
+int babe_stft_dist_partial(const float* X, const float* R, const float* w, double* part, int nblk, int B, int nbins,
+                           int frames, int mode, void* stream);
+int babe_stft_dist_grad(const float* X, const float* R, const float* w, const double* part, int nblk, float* G, int B,
+                        int nbins, int frames, int mode, int shared, void* stream);
 /* Alternative guidance distances of get_rec_grads (testing/blind_bwe_sampler.py:99-103; conf/tester/blind_bwe_cossim.yaml):
  * seed = d(distance)/d(rec) [* post] from r = y - rec.  mode 1: smooth_l1_loss(y, rec, reduction='sum', beta):
  * -clamp(r / beta, -1, 1).  mode 2: clamp(1 - CosineSimilarity(rec, y), min 0) per batch item, with the three sums
- * (rec.rec, rec.y, y.y) from babe_cos_partial (part: [B][nblk][3] doubles). */
+ * (rec.rec, rec.y, y.y) from babe_cos_partial (part: [B][nblk][3] doubles).  mode 3: r is already the gradient: out = r * post. */
 int babe_cos_partial(const float* r, long r_bs, const float* y, long y_bs, double* part, int nblk, int B, long n,
                      void* stream);
 int babe_residual_seed_alt(const float* r, long r_bs, const float* y, long y_bs, const double* part, int nblk,

@@ -75,7 +75,31 @@ def freq_weight(nbins, kind, dtype=torch.float32):
         return torch.ones_like(fr)
     if kind == "log":
         return torch.log2(1 + fr)
+    if kind == "quadratic":
+        return fr ** 2
+    if kind == "cubic":
+        return fr ** 3
+    if kind == "squared":
+        return fr ** 4
+    if kind == "logquadratic":
+        return torch.log2(1 + fr ** 2)
+    if kind == "logcubic":
+        return torch.log2(1 + fr ** 3)
     raise NotImplementedError(kind)
+
+
+def stft_distance(y, rec, nfft, weight="None", mag=False, logmag=False):
+    """apply_norm_STFT_fweighted :148-196 (mag=False) / apply_norm_STFTmag_fweighted :198-247: ONE scalar over the whole
+    batch, ||w (S(rec) - S(y))||_2, ||w|S(rec)| - w|S(y)|||_2 or the same on log10(w|S| + 1e-8)."""
+    X, Xr = torch.view_as_real(stft(rec, nfft)), torch.view_as_real(stft(y, nfft))        # [B, bins, frames, 2]
+    w = freq_weight(X.shape[1], weight, X.dtype).to(X.device)
+    if not mag:
+        return torch.linalg.norm((X * w[None, :, None, None] - Xr * w[None, :, None, None]).reshape(-1), ord=2)
+    Xm = torch.sqrt(X[..., 0] ** 2 + X[..., 1] ** 2) * w[None, :, None]
+    Xrm = torch.sqrt(Xr[..., 0] ** 2 + Xr[..., 1] ** 2) * w[None, :, None]
+    if logmag:
+        return torch.linalg.norm(torch.log10(Xm.reshape(-1) + 1e-8) - torch.log10(Xrm.reshape(-1) + 1e-8), ord=2)
+    return torch.linalg.norm(Xm.reshape(-1) - Xrm.reshape(-1), ord=2)
 
 
 def mag_loss(Xmag, Ymag, H, w):

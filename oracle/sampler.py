@@ -17,9 +17,10 @@ class OracleBlindSampler:
     def __init__(self, net, cqt, edm_params, *, fs, audio_len, T=35, order=2, xi=0.2, start_sigma=0.2,
                  nfft=4096, fc_init=(280, 285, 290, 295, 300), A_init=(-15, -17, -20, -25, -30),
                  mu=(1000.0, 10.0), tol=(5e-3, 5e-3), max_iter=100, fcmin=20.0, Amin=-50.0,
-                 weighting="sqrt", filter_out_cqt_DC_Nyq=True, norm=2, smoothl1_beta=1.0):
+                 weighting="sqrt", filter_out_cqt_DC_Nyq=True, norm=2, smoothl1_beta=1.0, stft_distance=None):
+        """stft_distance: None or dict(nfft=, weight=, mag=, logmag=) = posterior_sampling.stft_distance.use (:105-115)."""
         self.net, self.cqt, self.p = net, cqt, edm_params
-        self.norm, self.smoothl1_beta = norm, smoothl1_beta
+        self.norm, self.smoothl1_beta, self.stft_distance = norm, smoothl1_beta, stft_distance
         self.fs, self.audio_len, self.T, self.order, self.xi = fs, audio_len, T, order, xi
         self.start_sigma, self.nfft = start_sigma, nfft
         self.fc_init, self.A_init = fc_init, A_init
@@ -34,6 +35,8 @@ class OracleBlindSampler:
             return torch.nn.functional.smooth_l1_loss(y, rec, reduction="sum", beta=self.smoothl1_beta)
         if self.norm == "cosine":
             return (1 - torch.nn.functional.cosine_similarity(rec, y, dim=1, eps=1e-6)).clamp(min=0)
+        if self.stft_distance is not None:
+            return U.stft_distance(y, rec, **self.stft_distance)
         return torch.linalg.norm(y - rec, dim=1, ord=self.norm)
 
     def denoised(self, x, t):

@@ -759,7 +759,62 @@ def g16():
     save("sampler_altnorm.npz", **out)
 
 
+# ---------------------------------------------------------------- G17: STFT-domain guidance distances (get_rec_grads :105-115)
+def g17():
+    """posterior_sampling.stft_distance.use (conf/tester/blind_bwe_2.yaml: mag + logmag, nfft 2048, freq_weighting "None")
+    and the complex variant with a "sqrt" weighting: one guidance term at a fixed point + a T=3 blind run each."""
+    out = {}
+    for tag, mag, logmag, fw in (("logmag", True, True, "None"), ("complex", False, False, "sqrt")):
+        args = small_args(T=3)
+        net, sd = build_ref_net(args)
+        L = args.exp.audio_len
+
+        class ResidualNet:
+            def __init__(self, inner, a, sigma_data):
+                self.inner, self.a, self.sd = inner, a, sigma_data
+                self.CQTransform = inner.CQTransform
+
+            def __call__(self, x, cnoise):
+                return self.a * self.inner(x, cnoise) + (torch.exp(4 * cnoise) / self.sd) * x
+
+        ps = args.tester.posterior_sampling
+        ps.start_sigma = 0.05
+        ps.stft_distance.use, ps.stft_distance.mag, ps.stft_distance.logmag = True, mag, logmag
+        ps.stft_distance.use_multires, ps.stft_distance.nfft = False, 2048
+        ps.freq_weighting = fw
+        args.tester.blind_bwe.optimization.mu = [100, 1]
+        e = edm_mod.EDM(args)
+        with quiet():
+            s = samp_mod.BlindSampler(ResidualNet(net, 0.3, args.tester.diff_params.sigma_data), e, args)
+        g = torch.Generator().manual_seed(4242)
+        t_ax = torch.arange(L) / args.exp.sample_rate
+        clean = sum(0.05 / (k + 1) * torch.sin(2 * np.pi * 220.0 * (k + 1) * t_ax) * torch.exp(-t_ax * (1 + k)) for k in range(12))
+        clean = clean[None] + 0.1 * torch.randn(1, L, generator=g)
+        f = torch.fft.rfftfreq(4096, d=1 / args.exp.sample_rate)
+        Ht = bu.design_filter(torch.tensor([2000.0]), torch.tensor([-40.0]), f)
+        y = bu.apply_filter(clean, Ht, 4096)
+        noises = [torch.randn(1, L, generator=g) for _ in range(1 + args.tester.T)]
+        it = iter(noises)
+        orig_randn = torch.randn
+        torch.randn = lambda *a, **k: next(it)
+        try:
+            with quiet(), contextlib.redirect_stderr(io.StringIO()):
+                xres, fp, data_den, t, data_filt = s.predict_blind_bwe(y.clone(), rid=True)
+        finally:
+            torch.randn = orig_randn
+        out.update({"seed": 4242, "res_a": 0.3, "start_sigma": 0.05, "mu": [100.0, 1.0], "nfft": 2048, "y": y,
+                    f"x_{tag}": xres, f"filter_params_{tag}": fp, f"data_filters_{tag}": data_filt})
+        x0 = (0.05 * torch.randn(1, L, generator=g)).requires_grad_(True)
+        with quiet():
+            xd = s.get_denoised_estimate(x0, torch.tensor(0.04))
+            rg = s.get_rec_grads(xd, y, x0, torch.tensor(0.04),
+                                 lambda xx, fp_: bu.apply_filter(xx, bu.design_filter(fp_[0], fp_[1], f), 4096),
+                                 torch.tensor([[2000.0], [-40.0]]))
+        out.update({f"rg_x0_{tag}": x0.detach(), f"rg_{tag}": rg.detach()})
+    save("sampler_stftdist.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for w in which:
         globals()[w]()
