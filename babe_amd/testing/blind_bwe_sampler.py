@@ -65,8 +65,7 @@ class BlindSampler:
         self.smoothl1_beta = ps.get("smoothl1_beta", 1.0)
         if ps.SNR_observations != "None" or bb.get("sigma_den_estimate", 0):
             raise NotImplementedError("observation-noise regularisation (SNR_observations / sigma_den_estimate)")
-        if self.data_consistency:
-            raise NotImplementedError("data_consistency=True ('always False for blind bwe', conf/tester/blind_bwe.yaml)")
+
         assert batch_semantics in ("per_clip", "reference")
         self.batch_semantics = batch_semantics
         self.noise_device = noise_device
@@ -206,6 +205,17 @@ class BlindSampler:
             sm, y_sm = self.dc
             x0 = lincomb(torch.empty_like(x), 1.0, x, -float(t), d)
             x0 = lincomb(torch.empty_like(x), 1.0, mask_blend(sm, None, x0), 1.0, y_sm)
+            d = lincomb(torch.empty_like(x), 1.0 / float(t), x, -1.0 / float(t), x0)
+        elif self.data_consistency:
+            # posterior_sampling.data_consistency (conf/tester/blind_bwe_DC.yaml, bwe_formal_1000_DC.yaml): the classic
+            # replacement x0 <- y + x0 - A(x0) with the CURRENT degradation (:63-73; :178-188, :704-709, :748-753)
+            x0 = lincomb(torch.empty_like(x), 1.0, x, -float(t), d)
+            if self.fir_taps is not None:
+                a0 = fir_same(x0, self.fir_taps)
+            else:
+                H = st.design_filter(filter_params)
+                a0 = st.ola(st.filter_frames(st.stft(x0), H if H.shape[0] == B else H[0]), normalise=True)
+            x0 = lincomb(torch.empty_like(x), 1.0, x0, 1.0, y, -1.0, a0)
             d = lincomb(torch.empty_like(x), 1.0 / float(t), x, -1.0 / float(t), x0)
         return d, x_den, filter_params
 

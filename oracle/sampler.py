@@ -17,10 +17,12 @@ class OracleBlindSampler:
     def __init__(self, net, cqt, edm_params, *, fs, audio_len, T=35, order=2, xi=0.2, start_sigma=0.2,
                  nfft=4096, fc_init=(280, 285, 290, 295, 300), A_init=(-15, -17, -20, -25, -30),
                  mu=(1000.0, 10.0), tol=(5e-3, 5e-3), max_iter=100, fcmin=20.0, Amin=-50.0,
-                 weighting="sqrt", filter_out_cqt_DC_Nyq=True, norm=2, smoothl1_beta=1.0, stft_distance=None):
+                 weighting="sqrt", filter_out_cqt_DC_Nyq=True, norm=2, smoothl1_beta=1.0, stft_distance=None,
+                 data_consistency=False):
         """stft_distance: None or dict(nfft=, weight=, mag=, logmag=) = posterior_sampling.stft_distance.use (:105-115)."""
         self.net, self.cqt, self.p = net, cqt, edm_params
         self.norm, self.smoothl1_beta, self.stft_distance = norm, smoothl1_beta, stft_distance
+        self.data_consistency = data_consistency          # posterior_sampling.data_consistency (conf/tester/blind_bwe_DC.yaml)
         self.fs, self.audio_len, self.T, self.order, self.xi = fs, audio_len, T, order, xi
         self.start_sigma, self.nfft = start_sigma, nfft
         self.fc_init, self.A_init = fc_init, A_init
@@ -81,6 +83,12 @@ class OracleBlindSampler:
             for k, v in (("unet_fwd", t1 - t0), ("fit", t2 - t1), ("filter", t3 - t2), ("vjp", t4 - t3)):
                 timers[k] = timers.get(k, 0.0) + v
         score = (xd2 - x.detach()) / t ** 2 - rg
+        if self.data_consistency:
+            # replacement step on the Tweedie estimate (data_consistency_step_classic :63-73; :178-188, :704-709, :748-753)
+            x3 = score * t ** 2 + x.detach()
+            H = U.design_filter(params[0], params[1], self.freqs)
+            x3 = y + x3 - U.apply_filter(x3, H, self.nfft)
+            score = (x3 - x.detach()) / t ** 2
         return score, xd2, params
 
     def predict_blind_bwe(self, y, noises, blind=True, params=None, record=None):

@@ -533,3 +533,29 @@ def test_stft_distance_gradient_vs_autograd(mode, fw, tol):
     ops_ = STFTOps(nfft, L, 22050, torch.device("cuda"))
     g = ops_.distance_grad(rec.detach().cuda(), y.cuda(), freq_weights(ops_.nbins, fw).cuda(), mode, shared=True)
     assert rel(g, gref) < (tol or 2e-4), rel(g, gref)
+
+
+def test_blind_sampler_data_consistency():
+    """posterior_sampling.data_consistency=True (blind_bwe_DC.yaml / bwe_formal_1000_DC.yaml): replacement step on the
+    Tweedie estimate after every evaluation, blind and known-filter runs against the imported reference (G18)."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    s = load("sampler_dc.npz")
+    g, args, net = small_net(T=3, start_sigma=float(s["start_sigma"]))
+    args.tester.posterior_sampling.data_consistency = True
+    args.tester.blind_bwe.optimization.mu = [float(v) for v in s["mu"]]
+    args.tester.blind_bwe.optimization.max_iter = int(s["max_iter"])
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    smp = BlindSampler(ResidualNet(net, float(s["res_a"]), 0.063), EDM(args), args)
+    it = iter(noises)
+    smp._randn = lambda shape, device: next(it).to(device)
+    x, fp, dden, t, dfil = smp.predict_blind_bwe(s["y"].cuda(), rid=True)
+    for i in range(3):
+        assert params_close(dfil[i], s["data_filters"][i]), (i, dfil[i], s["data_filters"][i])
+    assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 2e-3 and params_close(fp, s["filter_params"])
+    it = iter(noises)
+    xk = smp.predict_bwe(s["y"].cuda(), torch.tensor([[2000.0], [-40.0]]), "fc_A")
+    assert rms_err(xk, s["x_known"]) < 1e-3 and rel(xk, s["x_known"]) < 2e-3
