@@ -866,7 +866,49 @@ def g18():
     save("sampler_dc.npz", **out)
 
 
+# ---------------------------------------------------------------- G19: filter fit / degradation on a 1024-point STFT
+def g19():
+    """tester.blind_bwe.NFFT = 1024 (conf/tester/blind_bwe_cocochorales.yaml, _vctk.yaml, _multislope.yaml, ...): T=3 blind run
+    with the 513-bin filter; harness of g7_8 with mu=[100,1]."""
+    args = small_args(T=3)
+    net, sd = build_ref_net(args)
+    L = args.exp.audio_len
+
+    class ResidualNet:
+        def __init__(self, inner, a, sigma_data):
+            self.inner, self.a, self.sd = inner, a, sigma_data
+            self.CQTransform = inner.CQTransform
+
+        def __call__(self, x, cnoise):
+            return self.a * self.inner(x, cnoise) + (torch.exp(4 * cnoise) / self.sd) * x
+
+    args.tester.posterior_sampling.start_sigma = 0.05
+    args.tester.blind_bwe.NFFT = 1024
+    args.tester.blind_bwe.optimization.mu = [100, 1]
+    e = edm_mod.EDM(args)
+    with quiet():
+        s = samp_mod.BlindSampler(ResidualNet(net, 0.3, args.tester.diff_params.sigma_data), e, args)
+    g = torch.Generator().manual_seed(4242)
+    t_ax = torch.arange(L) / args.exp.sample_rate
+    clean = sum(0.05 / (k + 1) * torch.sin(2 * np.pi * 220.0 * (k + 1) * t_ax) * torch.exp(-t_ax * (1 + k)) for k in range(12))
+    clean = clean[None] + 0.1 * torch.randn(1, L, generator=g)
+    f = torch.fft.rfftfreq(1024, d=1 / args.exp.sample_rate)
+    Ht = bu.design_filter(torch.tensor([2000.0]), torch.tensor([-40.0]), f)
+    y = bu.apply_filter(clean, Ht, 1024)
+    noises = [torch.randn(1, L, generator=g) for _ in range(1 + args.tester.T)]
+    it = iter(noises)
+    orig_randn = torch.randn
+    torch.randn = lambda *a, **k: next(it)
+    try:
+        with quiet(), contextlib.redirect_stderr(io.StringIO()):
+            xres, fp, data_den, t, data_filt = s.predict_blind_bwe(y.clone(), rid=True)
+    finally:
+        torch.randn = orig_randn
+    save("sampler_nfft1024.npz", seed=4242, res_a=0.3, start_sigma=0.05, mu=[100.0, 1.0], nfft=1024, y=y, x=xres,
+         filter_params=fp, data_filters=data_filt)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     for w in which:
         globals()[w]()

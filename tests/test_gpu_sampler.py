@@ -559,3 +559,25 @@ def test_blind_sampler_data_consistency():
     it = iter(noises)
     xk = smp.predict_bwe(s["y"].cuda(), torch.tensor([[2000.0], [-40.0]]), "fc_A")
     assert rms_err(xk, s["x_known"]) < 1e-3 and rel(xk, s["x_known"]) < 2e-3
+
+
+def test_blind_sampler_nfft_1024():
+    """tester.blind_bwe.NFFT = 1024 (blind_bwe_cocochorales.yaml - BASELINE configs[4] - _vctk.yaml, _multislope.yaml): the
+    513-bin STFT / filter design / fit / guidance kernels inside a T=3 blind run against the imported reference (G19)."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    s = load("sampler_nfft1024.npz")
+    g, args, net = small_net(T=3, start_sigma=float(s["start_sigma"]))
+    args.tester.blind_bwe.NFFT = int(s["nfft"])
+    args.tester.blind_bwe.optimization.mu = [float(v) for v in s["mu"]]
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    smp = BlindSampler(ResidualNet(net, float(s["res_a"]), 0.063), EDM(args), args)
+    it = iter(noises)
+    smp._randn = lambda shape, device: next(it).to(device)
+    x, fp, dden, t, dfil = smp.predict_blind_bwe(s["y"].cuda(), rid=True)
+    for i in range(3):
+        assert params_close(dfil[i], s["data_filters"][i]), (i, dfil[i], s["data_filters"][i])
+    assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 2e-3 and params_close(fp, s["filter_params"])

@@ -282,3 +282,23 @@ def test_sampler_data_consistency():
     assert rel(x, s["x"]) < 1e-3 and params_close(fp, s["filter_params"])
     xk, _ = smp.predict_blind_bwe(s["y"], noises, blind=False, params=torch.tensor([[2000.0], [-40.0]]))
     assert rel(xk, s["x_known"]) < 1e-3
+
+
+def test_sampler_nfft_1024():
+    """tester.blind_bwe.NFFT = 1024 (blind_bwe_cocochorales.yaml, _vctk.yaml, ...): 513-bin filter fit / degradation (G19)."""
+    g, sd, cqt = small_net()
+    s = load("sampler_nfft1024.npz")
+    L = 92092
+    a = float(s["res_a"])
+    p = E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10, Stmin=0, Stmax=50, Snoise=1.0)
+    net = lambda x, cn: a * UN.unet_forward(sd, CFG, cqt, x, cn) + (torch.exp(4 * cn) / 0.063) * x
+    smp = OracleBlindSampler(net, cqt, p, fs=22050, audio_len=L, T=3, start_sigma=float(s["start_sigma"]),
+                             mu=tuple(float(v) for v in s["mu"]), nfft=int(s["nfft"]))
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    rec = []
+    x, fp = smp.predict_blind_bwe(s["y"], noises, record=rec)
+    for i in range(3):
+        assert params_close(rec[i]["params"], s["data_filters"][i]), i
+    assert rel(x, s["x"]) < 1e-3 and params_close(fp, s["filter_params"])
