@@ -123,6 +123,7 @@ class _BandsStruct(C.Structure):
                 ("oct", C.c_void_p), ("binoct", C.c_void_p), ("tw4096", C.c_void_p),
                 ("nocts", C.c_int), ("binsoct", C.c_int), ("coef", C.c_void_p * 8),
                 ("wg_first", C.c_void_p), ("wg_count", C.c_void_p), ("nwg", C.c_int), ("abl", C.c_int),
+                ("max_wg_count", C.c_int), ("min_log2T", C.c_int), ("max_log2T", C.c_int),
                 ("sum_T", C.c_long), ("sum_M", C.c_long), ("sum_TlogT", C.c_double)]
 
 
@@ -247,6 +248,9 @@ class CQT_nsgt:
                 wgc.append(min(bpw, binsoct - s0))
         self._tabs["wg_first"], self._tabs["wg_count"] = ti(wgf), ti(wgc)
         self.nwg = len(wgf)
+        self._wg_max = int(max(wgc))
+        l2 = np.log2(d["T"]).astype(np.int64)
+        self._l2_range = (int(l2.min()), int(l2.max()))
         q = np.arange(2048, dtype=np.float64)
         self.tw4096 = tf(np.stack([np.cos(2 * np.pi * q / 4096), -np.sin(2 * np.pi * q / 4096)], -1)).contiguous()
         g, gd, Tw = d["g"], d["gdual"], d["Tw"]
@@ -271,7 +275,8 @@ class CQT_nsgt:
         for k in ("c", "M", "woff", "log2T", "oct", "binoct", "wg_first", "wg_count"):
             setattr(s, k, ptr(self._tabs[k]))
         s.nwg = self.nwg
-        s.abl = int(os.environ.get("BABE_CQT_ABL", "0"))
+        s.abl = 0                                         # (ablation builds only: tools/abl_build.sh -DBABE_CQT_ABL)
+        s.max_wg_count, (s.min_log2T, s.max_log2T) = self._wg_max, self._l2_range
         s.tw4096 = ptr(self.tw4096)
         s.nocts, s.binsoct = self.numocts, self.binsoct
         s.sum_T, s.sum_M = int(np.sum(d["T"])), int(np.sum(d["M"]))

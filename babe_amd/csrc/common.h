@@ -32,6 +32,26 @@ void babe_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Opt-in for more than 64 KB of dynamic LDS.  hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of the
+// kernel: `done` is a bitmask owned by the call site, bit = current device index, so a process that drives several GPUs
+// sets it on each of them (one process per GPU sets it once).  Returns the first HIP error, hipSuccess otherwise.
+#include <atomic>
+#include <initializer_list>
+static inline hipError_t babe_lds_optin(std::atomic<unsigned long long>& done, std::initializer_list<const void*> fns,
+                                        int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    for (const void* f : fns) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
+
 // Channel addressing of the (optionally two-source) conv input with bases and strides pinned in scalar registers.
 // Written as a per-lane select between kernarg fields (ci < split ? a.in_cs : a.in2_cs) the compiler emits a
 // dependent global load of the selected field plus s_waitcnt vmcnt(0) in every K-chunk, draining the prefetch queue.

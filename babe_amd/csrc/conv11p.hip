@@ -191,14 +191,10 @@ void launch11(const babe_conv_args& a, C11Geom g, hipStream_t s) {
     constexpr int WJ = (16 * BN / 4 + 255) / 256;
     const size_t lds = 3 * (size_t)(16 * 128 * NPW + WJ * 256 * 4) * 4;
     dim3 grid(g.tiles_t * tiles_f, g.CoutP / BN, a.B);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv11p_kernel<NT, NPW, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv11p_kernel<NT, NPW, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (babe_lds_optin(attr_done, {reinterpret_cast<const void*>(&conv11p_kernel<NT, NPW, true>),
+                                   reinterpret_cast<const void*>(&conv11p_kernel<NT, NPW, false>)}, (int)lds) != hipSuccess)
+        return;
     if (a.in_scale) hipLaunchKernelGGL((conv11p_kernel<NT, NPW, true>), grid, dim3(256), lds, s, a, g);
     else hipLaunchKernelGGL((conv11p_kernel<NT, NPW, false>), grid, dim3(256), lds, s, a, g);
 }

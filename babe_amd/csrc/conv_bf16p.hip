@@ -411,14 +411,10 @@ void launch_bf16p(const babe_conv_args& a, Bf16pGeom g, const unsigned short* wq
     dim3 grid(8 * ((g.total + 7) / 8));
     constexpr int WJ = (KW * G * BN + NTH - 1) / NTH;
     const size_t lds = 2 * (size_t)(G * 640 + WJ * NTH + 4) * 16;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, KW, true, UNITS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<G, KW, false, UNITS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (babe_lds_optin(attr_done, {reinterpret_cast<const void*>(&conv_bf16p_kernel<G, KW, true, UNITS>),
+                                   reinterpret_cast<const void*>(&conv_bf16p_kernel<G, KW, false, UNITS>)}, (int)lds) != hipSuccess)
+        return;
     if (a.in_scale) hipLaunchKernelGGL((conv_bf16p_kernel<G, KW, true, UNITS>), grid, dim3(NTH), lds, s, a, g, wq);
     else hipLaunchKernelGGL((conv_bf16p_kernel<G, KW, false, UNITS>), grid, dim3(NTH), lds, s, a, g, wq);
 }

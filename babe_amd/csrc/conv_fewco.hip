@@ -171,12 +171,8 @@ extern "C" int babe_conv2d_fewco(const babe_conv_args* ap, const float* w, int t
     if (split && lds < (size_t)7 * 32 * co * 16) lds = (size_t)7 * 32 * co * 16;      // the reduction reuses the weight image
 #define FEWCO_LAUNCH(COv, CSv)                                                                                      \
     {                                                                                                               \
-        static bool once = false;                                                                                   \
-        if (!once) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewco_kernel<COv, CSv>),                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);                      \
-            once = true;                                                                                            \
-        }                                                                                                           \
+        static std::atomic<unsigned long long> once{0};                                                             \
+        (void)babe_lds_optin(once, {reinterpret_cast<const void*>(&conv_fewco_kernel<COv, CSv>)}, 120 * 1024);      \
         hipLaunchKernelGGL((conv_fewco_kernel<COv, CSv>), dim3(cdiv(nq, 256 / CSv), a.B), dim3(256), lds,           \
                            (hipStream_t)stream, a, w, transpose_flip);                                              \
     }

@@ -367,14 +367,11 @@ void launch4p(const babe_conv_args& a, Wino4pGeom g, const float* wq, hipStream_
     size_t lds = 3 * (size_t)((XSOA ? 2 * 8 * 3 * (WC * 32) / 4 : 2 * 8 * (WC * 32)) + 2 * 8 * BN) * 16;
     const size_t ex = (size_t)WR * WC * 3072 * 4;
     if (ex > lds) lds = ex;
-    static bool attr_done = false;
-    if (!attr_done) {                       // 144 KB of dynamic LDS: above the 64 KB default cap
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4p_kernel<NTW, WR, WC, true, XSOA>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4p_kernel<NTW, WR, WC, false, XSOA>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};          // 144 KB of dynamic LDS: above the 64 KB default cap
+    if (babe_lds_optin(attr_done, {reinterpret_cast<const void*>(&conv_wino4p_kernel<NTW, WR, WC, true, XSOA>),
+                                   reinterpret_cast<const void*>(&conv_wino4p_kernel<NTW, WR, WC, false, XSOA>)},
+                       (int)lds) != hipSuccess)
+        return;                                                   // (the caller's BABE_LAUNCH_CHECK reports it)
     if (a.in_scale)
         hipLaunchKernelGGL((conv_wino4p_kernel<NTW, WR, WC, true, XSOA>), grid, dim3(128 * WR * WC), lds, s, a, g, wq);
     else

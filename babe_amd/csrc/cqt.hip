@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void band_fft_kernel(babe_cqt_bands bd, const 
     __shared__ int bt[3 * 64];
     const int wg = blockIdx.x, b = blockIdx.y;
     const int k0 = bd.wg_first[wg], nb = bd.wg_count[wg], lt = bd.log2T[k0];
+    if (nb > 64 || (nb << lt) > 4096) __builtin_trap();      // a table that contradicts its own summary fields: fail loudly
     // twiddle table -> LDS: loads issued first, written after (they are not needed before the second pass; the barrier at
     // the end of the load phase covers them)
     const float2* tw = reinterpret_cast<const float2*>(bd.tw4096);
@@ -259,12 +260,16 @@ __global__ __launch_bounds__(256) void band_fft_kernel(babe_cqt_bands bd, const 
     if (MODE == 0) __syncthreads();            // (synthesis needs the table only after its load-phase barrier)
 #pragma unroll
     for (int i = 0; i < 8; ++i) twl[threadIdx.x + i * 256] = twr[i];
+#ifdef BABE_CQT_ABL
     const int abl = bd.abl;
+#else
+    constexpr int abl = 0;
+#endif
     switch (lt) {
 #define CQ_CASE(L_) case L_: cq_run<L_, MODE>(bd, a, twl, bt, k0, nb, b, spec, bs, bs_stride, win, abl); break;
         CQ_CASE(12) CQ_CASE(11) CQ_CASE(10) CQ_CASE(9) CQ_CASE(8) CQ_CASE(7) CQ_CASE(6) CQ_CASE(5) CQ_CASE(4) CQ_CASE(3) CQ_CASE(2)
 #undef CQ_CASE
-        default: break;
+        default: __builtin_trap();
     }
 }
 
@@ -397,6 +402,11 @@ static int check_bands(const babe_cqt_bands* bd) {
     BABE_CHECK_ARG(bd && bd->nbands > 0 && bd->c && bd->M && bd->woff && bd->log2T && bd->oct && bd->binoct &&
                        bd->tw4096 && bd->nocts <= 8 && bd->wg_first && bd->wg_count && bd->nwg > 0,
                    "cqt: bad band table");
+    // what the band-FFT kernel relies on: <= 64 bands per workgroup (its LDS band table), T in 4..4096 (its dispatch)
+    BABE_CHECK_ARG(bd->max_wg_count >= 1 && bd->max_wg_count <= 64, "cqt: wg_count must be in 1..64 (got %d)", bd->max_wg_count);
+    BABE_CHECK_ARG(bd->min_log2T >= 2 && bd->max_log2T <= 12 && bd->min_log2T <= bd->max_log2T,
+                   "cqt: band lengths must be 2^2..2^12 (got 2^%d..2^%d)", bd->min_log2T, bd->max_log2T);
+    BABE_CHECK_ARG(bd->binsoct >= 1 && bd->nwg <= bd->nbands, "cqt: workgroup table inconsistent with the band table");
     return 0;
 }
 

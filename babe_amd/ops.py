@@ -182,11 +182,12 @@ def scale_gelu_units(x, scale, au):
     return au
 
 
-def conv2d_units(au, pc, out, Cin, dil=1, res=None, oscale=None, alpha=1.0, rbeta=1.0):
-    """out = alpha * conv(units, w) * oscale + rbeta * res with the input given as bf16 units (scale_gelu_units)."""
+def units_args(au, pc, out, Cin, dil=1, res=None, oscale=None, alpha=1.0, rbeta=1.0):
+    """ConvArgs of out = alpha * conv(units, w) * oscale + rbeta * res with the input given as bf16 units."""
     B, Cout, F, T = out.shape
     a = ConvArgs()
     nu = lib().babe_units_size(Cin, F, T)
+    assert au.dtype == torch.int16 and au.numel() >= B * nu * 8, "units buffer too small for this (Cin, F, T)"
     a.in_, a.in_bs, a.in_cs = ptr(au), nu, nu // (Cin // 8)
     a.in2, a.in2_bs, a.in2_cs, a.cin_split = None, 0, 0, Cin
     a.w_packed = None
@@ -202,6 +203,16 @@ def conv2d_units(au, pc, out, Cin, dil=1, res=None, oscale=None, alpha=1.0, rbet
     a.alpha, a.rbeta = alpha, rbeta
     a.B, a.Cin, a.Cout, a.F, a.T = B, Cin, Cout, F, T
     a.KH, a.KW, a.dil = pc.KH, pc.KW, dil
+    return a
+
+
+def units_supported(a):
+    """The library's own verdict (alignment, 2 GiB descriptor limits, BABE_CONV_BF16U): ask BEFORE writing units."""
+    return bool(lib().babe_conv2d_bf16_units_supported(C.byref(a)))
+
+
+def conv2d_units(au, pc, out, Cin, dil=1, res=None, oscale=None, alpha=1.0, rbeta=1.0, args=None):
+    a = args if args is not None else units_args(au, pc, out, Cin, dil, res, oscale, alpha, rbeta)
     check(lib().babe_conv2d_bf16_units(C.byref(a), ptr(pc.fwd), stream()), "conv2d_bf16_units")
     return out
 

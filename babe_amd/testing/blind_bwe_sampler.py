@@ -45,6 +45,8 @@ class BlindSampler:
         self.order = args.tester.order
         self.xi = ps.xi
         self.data_consistency = ps.data_consistency
+        self._dc_cfg = bool(ps.data_consistency)       # the blind loop reads the CONFIG value (:704, :748), never the
+        # attribute that predict_bwe_AR flips for good (:300); the known-filter loop reads the attribute (:178)
         self.nb_steps = args.tester.T
         bb = args.tester.blind_bwe
         self.mu = [bb.optimization.mu[0], bb.optimization.mu[1]]
@@ -57,13 +59,16 @@ class BlindSampler:
             raise NotImplementedError("posterior_sampling.norm must be 2, 'smoothl1' or 'cosine'")
         self.norm = ps.norm
         self.stft_dist = None
-        if ps.norm == 2 and ps.stft_distance.use:          # same precedence as get_rec_grads :99-117
-            if ps.stft_distance.use_multires:
+        # (older tester YAMLs - the conf/tester files written for a `testing.blind_bwe.*` package the reference no longer
+        # ships - have no stft_distance / SNR_observations keys: absent means off, tests/test_config_surface.py)
+        sdist = ps.get("stft_distance", None)
+        if ps.norm == 2 and sdist is not None and sdist.use:          # same precedence as get_rec_grads :99-117
+            if sdist.get("use_multires", False):
                 raise NotImplementedError("posterior_sampling.stft_distance.use_multires (auraloss multi-resolution loss)")
-            mode = (2 if ps.stft_distance.get("logmag", False) else 1) if ps.stft_distance.mag else 0
-            self.stft_dist = dict(nfft=int(ps.stft_distance.nfft), mode=mode, weight=ps.freq_weighting)
+            mode = (2 if sdist.get("logmag", False) else 1) if sdist.mag else 0
+            self.stft_dist = dict(nfft=int(sdist.nfft), mode=mode, weight=ps.freq_weighting)
         self.smoothl1_beta = ps.get("smoothl1_beta", 1.0)
-        if ps.SNR_observations != "None" or bb.get("sigma_den_estimate", 0):
+        if ps.get("SNR_observations", "None") != "None" or bb.get("sigma_den_estimate", 0):
             raise NotImplementedError("observation-noise regularisation (SNR_observations / sigma_den_estimate)")
 
         assert batch_semantics in ("per_clip", "reference")
@@ -206,7 +211,7 @@ class BlindSampler:
             x0 = lincomb(torch.empty_like(x), 1.0, x, -float(t), d)
             x0 = lincomb(torch.empty_like(x), 1.0, mask_blend(sm, None, x0), 1.0, y_sm)
             d = lincomb(torch.empty_like(x), 1.0 / float(t), x, -1.0 / float(t), x0)
-        elif self.data_consistency:
+        elif (self._dc_cfg if blind else self.data_consistency):
             # posterior_sampling.data_consistency (conf/tester/blind_bwe_DC.yaml, bwe_formal_1000_DC.yaml): the classic
             # replacement x0 <- y + x0 - A(x0) with the CURRENT degradation (:63-73; :178-188, :704-709, :748-753)
             x0 = lincomb(torch.empty_like(x), 1.0, x, -float(t), d)

@@ -160,7 +160,10 @@ typedef struct {
     /* workgroup table: workgroup w transforms bands wg_first[w] .. wg_first[w]+wg_count[w]-1, all of one octave
      * (same T), wg_count[w] * T <= 4096 points */
     const int* wg_first; const int* wg_count; int nwg;
-    int abl;             /* timing-only ablation bits (1: skip the FFT passes); 0 in production */
+    int abl;             /* timing-only ablation bits (1: skip the FFT passes); read only by -DBABE_CQT_ABL builds */
+    /* host-side summary of the DEVICE tables above, validated by the entry points (the kernel keeps wg_count bands of
+     * 3 ints in LDS and dispatches on log2T): max of wg_count (<= 64), min / max of log2T (2..12) */
+    int max_wg_count, min_log2T, max_log2T;
     long sum_T, sum_M;   /* sum over bands of T_k and M_k (for the measurement hook's algorithmic bytes) */
     double sum_TlogT;    /* sum over bands of T_k*log2(T_k) (algorithmic FFT flops = 5*that)            */
 } babe_cqt_bands;

@@ -908,7 +908,63 @@ def g19():
          filter_params=fp, data_filters=data_filt)
 
 
+# ---------------------------------------------------------------- G20: full-width blind sampler on the benchmark's composition
+def g20(mu=(100.0, 1.0), probe=False):
+    """testing/blind_bwe_sampler.py:619-769 at FULL width (Ns=[64,96,96,128,128,256,256], 44.1 kHz) on a 46046-sample
+    segment (1/8 of the benchmark's), T = 3 from sigma 0.05: two clips, each run by the imported reference at B = 1 with
+    its own recorded noise.  Step sizes mu = [100, 1]: with the default [1000, 10] the reference's own projected GD is
+    chaotic on these 23-frame segments (probe: a 1e-6 relative perturbation of y moves the reference's output by 2.8e-2 and
+    fc by 93 Hz - no fp32 implementation can be compared at 1e-3 against that), with [100, 1] the same perturbation moves
+    the output by 8e-6 (same setting as sampler_B2 / complete_recording).  The HIP test runs BOTH as one B = 2 per-clip batch on two
+    stream lanes - the composition bench.py times - so every (5,3) layer goes through conv_wino4p inside the sampler loop.
+    probe=True additionally reruns clip 0 with y perturbed by 1e-6 relative and prints how far the output moves (the
+    conditioning of the golden; not stored)."""
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_weights import full_width_sd
+    L, T = 46046, 3
+    args = ref_shim.load_args(exp="maestro44k_8s")
+    args.exp.audio_len = L
+    args.tester.T = T
+    args.tester.posterior_sampling.start_sigma = 0.05
+    args.tester.blind_bwe.optimization.mu = [float(mu[0]), float(mu[1])]
+    with quiet():
+        net = net_mod.Unet_CQT_oct_with_attention(args, "cpu")
+    net.load_state_dict(full_width_sd(0))
+    fs = args.exp.sample_rate
+    out = dict(res_a=0.3, start_sigma=0.05, mu=np.array(mu), L=L, T=T, wseed=0, seeds=np.array([7001, 7002]))
+    orig_randn = torch.randn
+
+    def run(seed, b, eps=0.0):
+        with quiet():
+            s = samp_mod.BlindSampler(ResidualNetRef(net, 0.3, args.tester.diff_params.sigma_data), edm_mod.EDM(args), args)
+        g = torch.Generator().manual_seed(seed)
+        y = synth_obs(L, fs, g, B=1, fc=3000.0 + 1500.0 * b, A=-30.0 - 10.0 * b)
+        if eps:
+            y = y * (1.0 + eps * torch.randn(y.shape, generator=torch.Generator().manual_seed(1)))
+        noises = [torch.randn(1, L, generator=g) for _ in range(1 + T)]
+        it = iter(noises)
+        torch.randn = lambda *a, **k: next(it)
+        t0 = time.time()
+        try:
+            with quiet(), contextlib.redirect_stderr(io.StringIO()):
+                xres, fp, data_den, t, data_filt = s.predict_blind_bwe(y.clone(), rid=True)
+        finally:
+            torch.randn = orig_randn
+        print(f"g20 clip {b}: reference run {time.time() - t0:.0f} s, filter {fp.tolist()}")
+        return y, torch.cat(noises, 0), xres, fp, data_den, t, data_filt
+
+    for b, seed in enumerate((7001, 7002)):
+        y, noises, xres, fp, data_den, t, data_filt = run(seed, b)
+        out.update({f"y{b}": y, f"noises{b}": noises, f"x{b}": xres, f"fp{b}": fp, f"den{b}": data_den, f"filt{b}": data_filt, "t": t})
+        if probe and b == 0:
+            _, _, x2, fp2, *_ = run(seed, b, eps=1e-6)
+            print("g20 conditioning: 1e-6 relative perturbation of y moves x by",
+                  float((x2 - xres).norm() / xres.norm()), "and the filter by", (fp2 - fp).abs().max().item())
+    save("sampler_full_46046.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     for w in which:
         globals()[w]()

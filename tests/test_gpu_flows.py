@@ -86,6 +86,16 @@ def test_complete_recording_flow_vs_reference_driver(use_denoiser):
                                                         typefilter="fc_A", denoiser=pre)
     key = "dn" if use_denoiser else "plain"
     assert smp.batch_semantics == "per_clip"                  # restored after the coupled blind step
+    if not use_denoiser:
+        # A SECOND recording on the same sampler: predict_bwe_AR flipped smp.data_consistency for good (the reference does,
+        # blind_bwe_sampler.py:300), but the blind loop reads the CONFIG value (:704, :748), so the blind estimate of the
+        # next recording must not pick up a replacement step.  Same seeds -> identical results.
+        assert smp.data_consistency is True and smp._dc_cfg is False
+        gn.manual_seed(int(s["noise_seed"]))
+        np.random.seed(int(s["np_seed"]))
+        out2, filt2, blind_pred2 = restore_recording_complete(smp, rec, n_segments_blindstep=2, ix_start=0, std=0.1,
+                                                              overlap_s=0.25, typefilter="fc_A", denoiser=None)
+        assert rel(blind_pred2, blind_pred) < 1e-5 and rel(filt2, filt) < 1e-5 and rel(out2, out) < 1e-5
     assert rel(blind_pred[:, ::16], s[f"{key}_blind_pred_sub16"]) < 2e-3
     fr = torch.from_numpy(s[f"{key}_blind_filter"])
     assert torch.allclose(filt.cpu()[0], fr[0], rtol=1e-2) and torch.allclose(filt.cpu()[1], fr[1], atol=1.0), (filt, fr)

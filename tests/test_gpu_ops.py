@@ -462,3 +462,35 @@ def test_bf16_units_path_is_bit_identical_to_fp32_staging(ops, B, C, Fq, T, dil)
     full[:, :, :, 1:T + 1] = a.to(torch.bfloat16).float().view(B, C // 8, 8, Fq, T).permute(0, 1, 3, 4, 2)
     want = full.view(B, C // 8, Fq, T // 4 + 1, 4, 8).permute(0, 1, 2, 4, 3, 5)
     assert torch.equal(u, want)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
+def test_large_lds_kernels_on_a_second_device(ops):
+    """hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute (csrc/common.h::babe_lds_optin): the kernels that
+    ask for more than 64 KB of LDS must launch on cuda:1 after they have run on cuda:0 in the same process."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 128, 64, 128, generator=g)
+    outs = []
+    for shape in ((128, 128, 5, 3), (128, 128, 1, 1)):             # conv_wino4p (144 KB) and conv11p
+        w = torch.randn(*shape, generator=g) / math.sqrt(128 * shape[2] * shape[3])
+        ref = UN.conv_same(x.double(), w.double(), 2 if shape[2] > 1 else 1)
+        for dev in ("cuda:0", "cuda:1"):
+            with torch.cuda.device(dev):
+                pc = ops.PackedConv(w.to(dev))
+                out = torch.empty(1, 128, 64, 128, device=dev)
+                ops.conv2d(x.to(dev), pc, out, dil=2 if shape[2] > 1 else 1)
+                torch.cuda.synchronize()
+            assert rel(out, ref) < 3e-6, (dev, shape)
+
+
+def test_gelu_one_exponential_form_is_within_fp32_roundoff_of_erf(ops):
+    """csrc/norm.hip evaluates Phi(u) by Abramowitz-Stegun 7.1.26 sharing one exponential with phi(u): bound the
+    deviation from the exact erf form over [-8, 8] - |gelu - exact| <= 1e-6 absolute (|u| Phi error 7.5e-8 * |u|, plus
+    fp32 round-off), i.e. below the conv kernels' own rounding at the activations' O(1) scale."""
+    u = torch.linspace(-8.0, 8.0, 64 * 4096).view(1, 8, 8, 4096).contiguous()
+    out = torch.empty_like(u, device="cuda")
+    ops.scale_gelu(u.cuda(), torch.ones(1, 8, device="cuda"), out)
+    exact = 0.5 * u.double() * (1.0 + torch.erf(u.double() / math.sqrt(2.0)))
+    err = (out.cpu().double() - exact).abs().max().item()
+    print(f"GELU (one-exponential form) max abs deviation from erf form on [-8, 8]: {err:.2e}")
+    assert err < 1e-6

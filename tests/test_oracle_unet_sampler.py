@@ -302,3 +302,29 @@ def test_sampler_nfft_1024():
     for i in range(3):
         assert params_close(rec[i]["params"], s["data_filters"][i]), i
     assert rel(x, s["x"]) < 1e-3 and params_close(fp, s["filter_params"])
+
+
+def test_sampler_full_width_vs_reference_golden():
+    """G20: the benchmarked composition at FULL width (Ns=[64,96,96,128,128,256,256], 44.1 kHz, L=46046, T=3) - oracle vs the
+    imported reference's predict_blind_bwe run at B = 1 (clip 0 of tests/golden/sampler_full_46046.npz; the GPU test runs
+    both clips as one per-clip batch on two stream lanes)."""
+    from tests.golden_weights import FULL_DILS, full_width_sd
+    s = load("sampler_full_46046.npz")
+    L, T, a = int(s["L"]), int(s["T"]), float(s["res_a"])
+    sd = full_width_sd(int(s["wseed"]))
+    cqt = CQT_nsgt(7, 64, "oct", ("kaiser", 1), 44100, L)
+    cfg = dict(num_octs=7, bins_per_oct=64, num_dils=FULL_DILS)
+    p = E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10, Stmin=0, Stmax=50, Snoise=1.0)
+    net = lambda x, cn: a * UN.unet_forward(sd, cfg, cqt, x, cn) + (torch.exp(4 * cn) / 0.063) * x
+    smp = OracleBlindSampler(net, cqt, p, fs=44100, audio_len=L, T=T, start_sigma=float(s["start_sigma"]),
+                             mu=tuple(float(v) for v in s["mu"]))
+    noises = [s["noises0"][i:i + 1] for i in range(T + 1)]
+    rec = []
+    x, fp = smp.predict_blind_bwe(s["y0"], noises, record=rec)
+    assert torch.equal(E.schedule(p, T, float(s["start_sigma"])), s["t"])
+    for i in range(T):
+        assert rel(rec[i]["x_den"], s["den0"][i]) < 1e-3, i
+        assert params_close(rec[i]["params"], s["filt0"][i]), i
+    rms = float((x - s["x0"]).pow(2).mean().sqrt())
+    assert rms < 1e-3 and rel(x, s["x0"]) < 1e-3, (rms, rel(x, s["x0"]))
+    assert params_close(fp, s["fp0"])
