@@ -26,6 +26,8 @@ _W = os.environ.get("BABE_CONV_WINO", "4")
 FEWCO = os.environ.get("BABE_CONV_FEWCO", "1") != "0"
 WINOGRAD = _W != "0"
 WINOGRAD4 = _W not in ("0", "2", "1")
+# nested Winograd F(2,5) x F(4,3) (csrc/conv_wino45.hip) for the (5,3) layers it supports; BABE_CONV_WINO45=0 switches it off
+WINOGRAD45 = WINOGRAD4 and os.environ.get("BABE_CONV_WINO45", "1") != "0"
 
 
 class PackedConv:
@@ -89,6 +91,12 @@ class PackedConv:
             self.bwd_wino4 = torch.empty(L.babe_conv_packed_size_wino4(self.Cout, self.Cin, self.KH, 1), device=w.device)
             check(L.babe_conv_pack_weights_wino4(ptr(w), ptr(self.fwd_wino4), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack_wino4")
             check(L.babe_conv_pack_weights_wino4(ptr(w), ptr(self.bwd_wino4), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino4")
+        self.fwd_wino45 = self.bwd_wino45 = None
+        if self.KH == 5 and self.KW == 3 and WINOGRAD45 and min(self.Cout, self.Cin) > 32:
+            self.fwd_wino45 = torch.empty(L.babe_conv_packed_size_wino45(self.Cout, self.Cin, 0), device=w.device)
+            self.bwd_wino45 = torch.empty(L.babe_conv_packed_size_wino45(self.Cout, self.Cin, 1), device=w.device)
+            check(L.babe_conv_pack_weights_wino45(ptr(w), ptr(self.fwd_wino45), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack_wino45")
+            check(L.babe_conv_pack_weights_wino45(ptr(w), ptr(self.bwd_wino45), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino45")
 
 
 def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=None, oscale=None, alpha=1.0, rbeta=0.0):
@@ -127,6 +135,8 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
         check(lib().babe_conv2d_bf16(C.byref(a), ptr(wq), pc.splits, stream()), "conv2d_bf16")
     elif FEWCO and getattr(pc, "w_raw", None) is not None and Cout <= 4 and lib().babe_conv2d_fewco_supported(C.byref(a)):
         check(lib().babe_conv2d_fewco(C.byref(a), ptr(pc.w_raw), int(transpose), stream()), "conv2d_fewco")
+    elif getattr(pc, "fwd_wino45", None) is not None and lib().babe_conv2d_wino45_supported(C.byref(a)):
+        check(lib().babe_conv2d_wino45(C.byref(a), ptr(pc.bwd_wino45 if transpose else pc.fwd_wino45), stream()), "conv2d_wino45")
     elif getattr(pc, "fwd_wino4", None) is not None and lib().babe_conv2d_wino4_supported(C.byref(a)):
         check(lib().babe_conv2d_wino4(C.byref(a), ptr(pc.bwd_wino4 if transpose else pc.fwd_wino4), stream()), "conv2d_wino4")
     elif getattr(pc, "fwd_wino", None) is not None and lib().babe_conv2d_wino_supported(C.byref(a)):

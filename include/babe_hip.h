@@ -84,6 +84,16 @@ int babe_conv2d_wino4_supported(const babe_conv_args* a);
 int babe_conv_pack_weights_wino4(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
                                  void* stream);
 long babe_conv_packed_size_wino4(int Cout, int Cin, int KH, int transpose_flip);
+/* NESTED Winograd variant (csrc/conv_wino45.hip, round 3): F(2,5) along frequency x F(4,3) along time, 4.5 multiplies per
+ * output instead of 7.5 (0.6 of the F(4,3) kernel's matrix work, 0.3 of the direct kernel's), fp32 MFMA, rounding error
+ * about 3.4x the F(4,3) kernel's (2-3e-6 relative).  Replaces the same F.conv2d call (cqtdiff+.py:85) and its input-VJP.
+ * w_wino45 from babe_conv_pack_weights_wino45: [3 passes][ceil8(Cin)][ceil64(Cout)][12].  Needs KH x KW = 5 x 3,
+ * T % 4 == 0, T >= 64, Cin >= 8, Cout > 32, 16-byte aligned in/out/res rows, cin_split % 8 == 0, source views < 1 GiB. */
+int babe_conv2d_wino45(const babe_conv_args* a, const float* w_wino45, void* stream);
+int babe_conv2d_wino45_supported(const babe_conv_args* a);
+int babe_conv_pack_weights_wino45(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
+                                  void* stream);
+long babe_conv_packed_size_wino45(int Cout, int Cin, int transpose_flip);
 /* (KH,3) conv with at most 4 OUTPUT channels on the vector ALU (csrc/conv_fewco.hip): the input-VJP of the UNet's 2-channel
  * pyramid projections (cqtdiff+.py:676, 794).  w is in the REFERENCE layout, not packed: [Cout][Cin][KH][3] for
  * transpose_flip = 0; for transpose_flip = 1 the weights [Cin][Cout][KH][3] of the conv whose input-VJP is computed (a->Cin,
