@@ -32,6 +32,13 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ABL: compile-time ablation bits for profiling builds (tools/abl_build.sh conv_wino45 <mask>): 1 no activation loads,
+// 2 no MFMA, 4 no operand LDS reads, 8 no input transform / LDS stores, 16 no barrier, 32 no weight DMA, 64 every slab
+// loads channel 0, 128 loads into registers nobody reads (no waits for load data), 256 counted vmcnt at the barrier; 64 = slabs load channel 0 (cache-resident loads: same instructions, no memory-side traffic)
+#ifndef ABL
+#define ABL 0
+#endif
+
 namespace {
 
 struct Wino45Geom {
@@ -77,21 +84,39 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
     const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(HAS_ISC ? a.in_scale + (long)b * a.Cin : a.in), 0, HAS_ISC ? a.Cin * 4 : 0, 0x00020000);
 
-    // ---- per-thread staging constants: thread = (ci, unit), unit = rp * 16 + tu
-    const int s_tu = tid & 15, s_rp = (tid >> 4) & 3, s_ci = tid >> 6;
+    // ---- per-thread staging constants: thread = (ci = wave, unit = lane), unit = rp * 16 + tu.
+    // fp32 MFMA and vector-ALU instructions do NOT overlap on this hardware (tools/mfma_valu_coexec.hip: a loop of
+    // v_mfma_f32_16x16x4_f32 slows down by the full issue time of every v_fma / v_mov put beside it, 3-4 ns per wave
+    // instruction at two waves per SIMD; ds_read and SALU do overlap), so every vector instruction of the staging path is
+    // paid in matrix-pipe time.  Hence: the channel and slab part of a load address travels in the SCALAR offset of the buffer
+    // instruction (one input channel per wave), the per-lane part is a loop constant, coefficients are SGPRs, neighbour
+    // samples come by DPP, and the slab body is one straight line (branches made hipcc shuffle 100+ registers per slab).
+    const int s_tu = lane & 15, s_rp = lane >> 4;
     const int s_t = t0 + 4 * s_tu;
     const int s_fa = cls + 2 * (grp * 4 + s_rp) * a.dil;             // first output row of the pair
-    unsigned er[6];                                                     // byte offset of (row r, t) or OOBH
+    // Neighbour samples t-1 and t+4 come from the adjacent lanes (same row, tu -+ 1) by DPP row shifts; only the first lane of
+    // a 16-lane DPP row needs t-1 from memory and only the last one t+4.  ONE dword load per slab fetches all 48 of them for
+    // the wave - lane L < 48 loads the sample of (row L >> 3, row pair (L >> 1) & 3, side L & 1) - and ds_bpermute hands
+    // each to the lane that needs it.  A vector-memory instruction costs about 8 ns of CU time next to fp32 MFMAs whether it
+    // moves 1 KB or nothing (ablations in DESIGN.md 8), so their NUMBER is what the staging path minimises.
+    unsigned er[6];                                                     // byte offset of (row r, t), or OOBH
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         const int fr = s_fa + (r - 2) * a.dil;
         const bool ok = fr >= 0 && fr < a.F && s_t < a.T;
         er[r] = ok ? (unsigned)((fr * a.T + s_t) * 4) : OOBH;
     }
-    const unsigned leftbad = s_t > 0 ? 0u : OOBH;
-    const unsigned rightbad = s_t + 4 < a.T ? 0u : OOBH;
-    const int xcs1 = s_ci * cs1 * 4, xcs2 = s_ci * cs2 * 4;           // bytes
-    const int xlds = (s_ci * NU + (tid & 63)) * 3;                     // float4 index of this thread's 12 floats
+    unsigned ehalo = OOBH;
+    {
+        const int hr = lane >> 3, hg = (lane >> 1) & 3, hs = lane & 1;
+        const int fr = cls + 2 * (grp * 4 + hg) * a.dil + (hr - 2) * a.dil;
+        const int th = hs ? t0 + 64 : t0 - 1;
+        if (lane < 48 && fr >= 0 && fr < a.F && th >= 0 && th < a.T) ehalo = (unsigned)((fr * a.T + th) * 4);
+    }
+    // bpermute source (byte index) of row 0 for this lane: its row pair's left sample, or the right one for the last lane of
+    // the DPP row; row r adds 32 bytes through the instruction's offset field
+    const int hsrc = (2 * s_rp + (s_tu == 15 ? 1 : 0)) * 4;
+    const int xlds = tid * 3;                                           // float4 index of this thread's 12 floats
     int wvo[WJ];
 #pragma unroll
     for (int jj = 0; jj < WJ; ++jj) {
@@ -107,45 +132,105 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
 #pragma unroll
         for (int p = 0; p < 12; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging registers: raw loads of the slab that is next to be transformed
+    // staging registers: raw loads of the slab that is next to be transformed.  Rows 0 and 5 of the patch are read by pass 2
+    // (phases 0, 5) only: they are loaded behind a wave-uniform branch in that pass and hold zeros before it (their
+    // coefficients are 0 in passes 0 and 1 anyway).
     f32x4 xv[6];
-    float xl[6], xr[6], xsc = 1.f;
-
-    // rows 0 and 5 of the patch are read by pass 2 (phases 0, 5) only: in the other passes their offsets are forced out of
-    // range, so the loads return 0 without touching memory and the code stays one straight line
-    auto issue_act = [&](int ps, int ci0) {
+    f32x4 xdummy[6];                                     // (ABL & 128 only: load destinations nobody waits for)
+    float xhl = 0.f, xsc = 1.f;                          // xhl: the wave's 48 halo samples, one per lane
+#pragma unroll
+    for (int r = 0; r < 6; r += 5) xv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // rows r0 .. r1-1 of the patch of slab (ps, ci0).  The loads of a slab are issued a few at a time BETWEEN the MFMA groups:
+    // issued back to back by all eight waves they queue up in front of the CU's one address unit and every wave sits in
+    // its load-issue phase at the same time (ablation: 240 of 750 us on the 256-channel layers).
+    // (`s2 ? +p2 : +p1`: the unary plus makes the conditional a VALUE - on two captured lvalues clang selects between their
+    // ADDRESSES, which keeps p1 / p2 / nb1 / nb2 in scratch memory and turns every buffer instruction into a waterfall loop)
+    auto issue_rows = [&](int ps, int ci0, int r0, int r1) __attribute__((always_inline)) {
+        if (ABL & 1) return;
         const bool s2 = ci0 >= split;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(s2 ? p2 : p1), 0, s2 ? nb2 : nb1, 0x00020000);
-        const unsigned sb = (unsigned)((s2 ? (ci0 - split) * cs2 : ci0 * cs1) * 4) + (unsigned)(s2 ? xcs2 : xcs1);
-        const unsigned edge = ps == 2 ? 0u : OOBH;                    // scalar
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(s2 ? +p2 : +p1), 0, s2 ? +nb2 : +nb1, 0x00020000);
+        const int so = (ABL & 64) ? 0 : (s2 ? (ci0 - split + wave) * cs2 : (ci0 + wave) * cs1) * 4;   // scalar: channel of this wave
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            const unsigned e = (er[r] + sb) | ((r == 0 || r == 5) ? edge : 0u);
-            xv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, e, 0, 0));
-            xl[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (e - 4u) | leftbad, 0, 0));
-            xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (e + 16u) | rightbad, 0, 0));
+            if (r < r0 || r >= r1) continue;
+            if (ABL & 128) xdummy[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, er[r], so, 0));
+            else xv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, er[r], so, 0));
         }
-        if (HAS_ISC) xsc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, (s_ci + ci0) * 4, 0, 0));
+    };
+    auto issue_halo = [&](int ci0) __attribute__((always_inline)) {
+        if (ABL & 1) return;
+        const bool s2 = ci0 >= split;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(s2 ? +p2 : +p1), 0, s2 ? +nb2 : +nb1, 0x00020000);
+        const int so = (ABL & 64) ? 0 : (s2 ? (ci0 - split + wave) * cs2 : (ci0 + wave) * cs1) * 4;
+        xhl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ehalo, so, 0));
+    };
+    auto issue_isc = [&](int ci0) __attribute__((always_inline)) {
+        if (HAS_ISC) xsc = a.in_scale[(long)b * a.Cin + ci0 + wave];          // one channel per wave: a scalar load
+    };
+    auto issue_act = [&](int ps, int ci0) __attribute__((always_inline)) {              // (prologue: everything at once)
+        issue_rows(ps, ci0, 1, 5);
+        if (ps == 2) {
+            issue_rows(ps, ci0, 0, 1);
+            issue_rows(ps, ci0, 5, 6);
+        }
+        issue_halo(ci0);
+        issue_isc(ci0);
+    };
+    // lane i <- src of lane i-1 / i+1 inside its 16-lane row; the row's first / last lane keeps `old` (its own halo load).
+    // Inline asm: hipcc 7.2 miscompiles __builtin_amdgcn_update_dpp on element 3 of a loaded vector (it reads element 0).
+    // NOT `asm volatile`: a side-effecting asm statement inside these by-reference lambdas keeps the captured locals (source
+    // pointers, strides) in scratch memory, and every buffer instruction then gets a waterfall loop around its descriptor.
+    auto dpp_shr1 = [](float old, float src) __attribute__((always_inline)) {
+        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+        return old;
+    };
+    auto dpp_shl1 = [](float old, float src) __attribute__((always_inline)) {
+        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+        return old;
     };
     // frequency phases of pass ps from the 6 rows d0..d5 of one column:
     //   e = d4 - k2 d2,  o = k3 d3 - k1 d1,  Ea = x0 d0 + e + za o,  Eb = x5 d5 + ye e - o
     //   (1,2): k2 4, k1 4, k3 1, x0 0, za 1, x5 0, ye 1      (3,4): k2 1, k1 2, k3 2, x0 0, za 1, x5 0, ye 1
     //   (0,5): k2 5, k1 4, k3 5, x0 4, za 0, x5 1, ye 0      (Ea = 4 d0 - 5 d2 + d4,  Eb = 4 d1 - 5 d3 + d5)
-    auto store_act = [&](int ps, f32x4* buf) {
-        const float k2 = ps == 0 ? 4.f : (ps == 1 ? 1.f : 5.f);
-        const float k1 = ps == 1 ? 2.f : 4.f;
-        const float k3 = ps == 0 ? 1.f : (ps == 1 ? 2.f : 5.f);
-        const float x0 = ps == 2 ? 4.f : 0.f, za = ps == 2 ? 0.f : 1.f;
-        const float x5 = ps == 2 ? 1.f : 0.f, ye = ps == 2 ? 0.f : 1.f;
+    // (coefficients selected as integers so that they stay in scalar registers)
+    auto fsel = [](int ps, unsigned c0, unsigned c1, unsigned c2) __attribute__((always_inline)) {
+        return __builtin_bit_cast(float, ps == 0 ? c0 : (ps == 1 ? c1 : c2));
+    };
+    // time transform (same B^T): U0 = 4E0-5E2+E4, U1/U2 = (E4-4E2) +- (E3-4E1), U3/U4 = (E4-E2) +- 2(E3-E1), U5 = 4E1-5E3+E5
+    auto tt = [](const float (&E)[6], float (&U)[6]) {
+        const float e = E[4] - 4.f * E[2], o = E[3] - 4.f * E[1];
+        const float e2 = E[4] - E[2], o2 = E[3] - E[1];
+        U[0] = 4.f * E[0] + (E[4] - 5.f * E[2]);
+        U[1] = e + o;
+        U[2] = e - o;
+        U[3] = e2 + 2.f * o2;
+        U[4] = e2 - 2.f * o2;
+        U[5] = 4.f * E[1] + (E[5] - 5.f * E[3]);
+    };
+    auto store_act = [&](int ps, f32x4* buf) __attribute__((always_inline)) {
+        if (ABL & 8) return;
+        const float k2 = fsel(ps, 0x40800000u, 0x3f800000u, 0x40a00000u);        // 4 1 5
+        const float k1 = fsel(ps, 0x40800000u, 0x40000000u, 0x40800000u);        // 4 2 4
+        const float k3 = fsel(ps, 0x3f800000u, 0x40000000u, 0x40a00000u);        // 1 2 5
+        const float x0 = fsel(ps, 0u, 0u, 0x40800000u), za = fsel(ps, 0x3f800000u, 0x3f800000u, 0u);
+        const float x5 = fsel(ps, 0u, 0u, 0x3f800000u), ye = za;
+        float xh[6];                                      // row r: left sample in the first lane of a DPP row, right one in the last
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            asm("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(xh[r]) : "v"(hsrc), "v"(xhl), "n"(32 * r));
+        // hipcc does not know that the statements above complete asynchronously: every later use of xh[] (register copies
+        // included) is made to depend on this wait
+        asm("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]), "+v"(xh[5]));
         float Ea[6], Eb[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             float d[6];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) d[r] = j == 0 ? xl[r] : (j == 5 ? xr[r] : xv[r][j - 1]);
+            for (int r = 0; r < 6; ++r)
+                d[r] = j == 0 ? dpp_shr1(xh[r], xv[r][3]) : (j == 5 ? dpp_shl1(xh[r], xv[r][0]) : xv[r][j - 1]);
             const float e = d[4] - k2 * d[2];
             const float o = k3 * d[3] - k1 * d[1];
-            Ea[j] = x0 * d[0] + (e + za * o);
+            Ea[j] = x0 * d[0] + (za * o + e);
             Eb[j] = x5 * d[5] + (ye * e - o);
         }
         if (HAS_ISC) {
@@ -155,17 +240,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
                 Eb[j] *= xsc;
             }
         }
-        // time transform (same B^T): U0 = 4E0-5E2+E4, U1/U2 = (E4-4E2) +- (E3-4E1), U3/U4 = (E4-E2) +- 2(E3-E1), U5 = 4E1-5E3+E5
-        auto tt = [](const float (&E)[6], float (&U)[6]) {
-            const float e = E[4] - 4.f * E[2], o = E[3] - 4.f * E[1];
-            const float e2 = E[4] - E[2], o2 = 2.f * (E[3] - E[1]);
-            U[0] = 4.f * E[0] - 5.f * E[2] + E[4];
-            U[1] = e + o;
-            U[2] = e - o;
-            U[3] = e2 + o2;
-            U[4] = e2 - o2;
-            U[5] = 4.f * E[1] - 5.f * E[3] + E[5];
-        };
         float Ua[6], Ub[6];
         tt(Ea, Ua);
         tt(Eb, Ub);
@@ -173,13 +247,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
         buf[xlds + 1] = f32x4{Ua[4], Ua[5], Ub[0], Ub[1]};
         buf[xlds + 2] = f32x4{Ub[2], Ub[3], Ub[4], Ub[5]};
     };
-    auto dma_w = [&](int ps, int ci0, f32x4* buf, int j0, int j1) {
+    auto dma_w = [&](int ps, int ci0, f32x4* buf, int j0, int j1) __attribute__((always_inline)) {
+        if (ABL & 32) return;
         const int so = ((ps * g.CinP + ci0) * g.CoutP + co0) * 48;     // bytes, scalar
 #pragma unroll
         for (int jj = j0; jj < j1; ++jj)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(buf + XSZ + jj * NTH + wave * 64), 16, wvo[jj], so, 0, 0);
     };
-    auto advance = [&](int& ps, int& ci0) {             // next slab, clamped at the last one
+    auto advance = [&](int& ps, int& ci0) __attribute__((always_inline)) {             // next slab, clamped at the last one
         int nc = ci0 + KC, np = ps;
         if (nc >= g.CinP) {
             nc = 0;
@@ -209,7 +284,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
     advance(pA, cA);
     advance(pW, cW);
     issue_act(pA, cA);                            // slab 2 (or a clamped copy of the last slab)
-    int pS = pA;                                  // pass of the data held in the staging registers
     __syncthreads();
 
     f32x4 av[2], bv[2][2];
@@ -226,42 +300,50 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
         const f32x4* Xn = smem + rn * BUF;
         f32x4* Xw = smem + rw * BUF;
 #define MFMA_GRP(c, pg)                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
+    if (!(ABL & 2)) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
         acc[0][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][0][i], acc[0][4 * (pg) + i], 0, 0, 0); \
         acc[1][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][1][i], acc[1][4 * (pg) + i], 0, 0, 0); \
     }
 #define READ_GRP(c, base, ks, pg)                                                   \
-    av[c] = (base)[aoff + (ks) * 4 * BN * 3 + (pg)];                                \
-    bv[c][0] = (base)[boff + (ks) * 4 * NU * 3 + (pg)];                             \
-    bv[c][1] = (base)[boff + (ks) * 4 * NU * 3 + 16 * 3 + (pg)];
-        // group (ks 0, pg 0): transform + write the staged activations of slab j+2, re-issue the staging loads (slab j+3),
-        // first part of the weight DMA of slab j+2
-        READ_GRP(1, Xs, 0, 1)
-        store_act(pS, Xw);
+    if (!(ABL & 4) || j == 0) {                                                     \
+        av[c] = (base)[aoff + (ks) * 4 * BN * 3 + (pg)];                            \
+        bv[c][0] = (base)[boff + (ks) * 4 * NU * 3 + (pg)];                         \
+        bv[c][1] = (base)[boff + (ks) * 4 * NU * 3 + 16 * 3 + (pg)];                \
+    }
+#define GROUP(cr, base, ks, pg, cm, pgm)       \
+    READ_GRP(cr, base, ks, pg)                 \
+    MFMA_GRP(cm, pgm)                          \
+    __builtin_amdgcn_sched_barrier(0);
+        // staging of slab j+2: transform + write of the activations held in the staging registers; then, spread over the
+        // MFMA groups, its weight DMA and the loads of slab j+3 into the freed registers (rows 0 / 5, which only pass 2
+        // reads, last)
+        store_act(pA, Xw);
         advance(pA, cA);
-        issue_act(pA, cA);
-        pS = pA;
-        dma_w(pW, cW, Xw, 0, 2);
-        MFMA_GRP(0, 0)
+        issue_isc(cA);
         __builtin_amdgcn_sched_barrier(0);
-        READ_GRP(0, Xs, 0, 2)
-        dma_w(pW, cW, Xw, 2, WJ);
-        MFMA_GRP(1, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        READ_GRP(1, Xs, 1, 0)
-        MFMA_GRP(0, 2)
-        __builtin_amdgcn_sched_barrier(0);
-        READ_GRP(0, Xs, 1, 1)
-        MFMA_GRP(1, 0)
-        __builtin_amdgcn_sched_barrier(0);
-        READ_GRP(1, Xs, 1, 2)
-        MFMA_GRP(0, 1)
-        __builtin_amdgcn_sched_barrier(0);
+        dma_w(pW, cW, Xw, 0, 1);
+        issue_rows(pA, cA, 1, 3);
+        GROUP(1, Xs, 0, 1, 0, 0)
+        dma_w(pW, cW, Xw, 1, 2);
+        issue_rows(pA, cA, 3, 5);
+        GROUP(0, Xs, 0, 2, 1, 1)
+        dma_w(pW, cW, Xw, 2, 3);
+        issue_halo(cA);
+        GROUP(1, Xs, 1, 0, 0, 2)
+        if (pA == 2) {                             // rows 0 and 5: phases 0 and 5 only
+            issue_rows(pA, cA, 0, 1);
+            issue_rows(pA, cA, 5, 6);
+        }
+        GROUP(0, Xs, 1, 1, 1, 0)
+        GROUP(1, Xs, 1, 2, 0, 1)
         // last group: first operands of slab j+1 (its buffer was completed by the PREVIOUS barrier)
         advance(pW, cW);
         READ_GRP(0, Xn, 0, 0)
         MFMA_GRP(1, 2)
-        __syncthreads();                           // slab j+2 complete (DMA + ds_write), slab j's buffer free
+        if (ABL & 128) {                           // (timing only: the DMAs may not have landed)
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            __builtin_amdgcn_s_barrier();
+        } else if (!(ABL & 16)) __syncthreads();   // slab j+2 complete (DMA + ds_write), slab j's buffer free
         rb = rn;
         // pass boundary: carry the finished phases into the accumulators of the next pass (see the header)
         cM += KC;
@@ -291,6 +373,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
     }
 #undef MFMA_GRP
 #undef READ_GRP
+#undef GROUP
+    if (ABL & 128) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) asm volatile("" ::"v"(xdummy[r]));
+    }
 
     // ---- output: rows fa (from M_0) and fa + dil (from M_5), time transform A4^T; lane = (unit l15, channels 4 lk .. 4 lk + 3)
     const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
@@ -408,9 +495,10 @@ extern "C" int babe_conv2d_wino45_supported(const babe_conv_args* ap) {
     static const char* ov = getenv("BABE_CONV_WINO45");
     if (ov && ov[0] == '0') return 0;
     const babe_conv_args& a = *ap;
-    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    auto al16 = [](const void* p) __attribute__((always_inline)) { return ((uintptr_t)p & 15) == 0; };
     if (a.KH != 5 || a.KW != 3 || a.T % 4 != 0 || a.T < 64 || a.dil < 1) return 0;   // (tiles are 64 time steps wide)
-    if (a.Cin < 8 || a.Cout < 33) return 0;                  // (few-channel convs: conv_fewco / direct kernels)
+    if (a.Cin < 8 || a.Cin % 8 != 0 || a.Cout < 33) return 0;   // (the channel part of a load address is a scalar offset,
+    // which the buffer range check does not cover: no padded input channels; few-channel convs run on conv_fewco / direct)
     if (!al16(a.in) || a.in_bs % 4 || a.in_cs % 4) return 0;
     if (a.in2 && (!al16(a.in2) || a.in2_bs % 4 || a.in2_cs % 4)) return 0;
     if (!al16(a.out) || a.out_bs % 4 || a.out_cs % 4) return 0;
