@@ -47,6 +47,7 @@ _SIGS = {
     "babe_conv_pack_weights_wino4": [_P, _P, _I, _I, _I, _I, _I, _P],
     "babe_conv2d_wino45": [C.POINTER(ConvArgs), _P, _P],
     "babe_conv2d_wino45_supported": [C.POINTER(ConvArgs)],
+    "babe_conv2d_wino45_preferred": [C.POINTER(ConvArgs)],
     "babe_conv_pack_weights_wino45": [_P, _P, _I, _I, _I, _I, _I, _P],
     "babe_conv_pack_weights_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "babe_gn_partial": [_P, _P, _I, _I, _L, _I, _P],

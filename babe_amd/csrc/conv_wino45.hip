@@ -34,7 +34,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ABL: compile-time ablation bits for profiling builds (tools/abl_build.sh conv_wino45 <mask>): 1 no activation loads,
 // 2 no MFMA, 4 no operand LDS reads, 8 no input transform / LDS stores, 16 no barrier, 32 no weight DMA, 64 every slab
-// loads channel 0, 128 loads into registers nobody reads (no waits for load data), 256 counted vmcnt at the barrier; 64 = slabs load channel 0 (cache-resident loads: same instructions, no memory-side traffic)
+// loads channel 0 (cache-resident loads: same instructions, no memory-side traffic).  NB: with the loads or the transform
+// removed hipcc also removes whatever became dead (ablation 1 drops the transform arithmetic too) (cache-resident loads: same instructions, no memory-side traffic)
 #ifndef ABL
 #define ABL 0
 #endif
@@ -71,18 +72,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
     const int grp = rest % g.groups;
     const int cls = rest / g.groups;                    // residue class of the tile's rows (mod dil)
     const int t0 = tile_t * 64;
-    const int split = a.in2 ? a.cin_split : a.Cin;
     const int nci = g.CinP / KC;
     const int nslab = 3 * nci;
 
-    // ---- descriptors
+    // ---- descriptors (ONE source: every (5,3) conv of the UNet reads a single tensor - the two-source inputs of the decoder
+    // go through (1,1) convs - and a `second ? a : b` on pointers captured by the staging lambdas put them in scratch memory)
     const float* p1 = a.in + (long)b * a.in_bs;
-    const float* p2 = a.in2 ? a.in2 + (long)b * a.in2_bs : p1;
-    const int cs1 = (int)a.in_cs, cs2 = a.in2 ? (int)a.in2_cs : (int)a.in_cs;
-    const int nb1 = split * cs1 * 4, nb2 = (a.Cin - split) * cs2 * 4;
+    const int cs1 = (int)a.in_cs;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p1, 0, a.Cin * cs1 * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, 3 * g.CinP * g.CoutP * 48, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(HAS_ISC ? a.in_scale + (long)b * a.Cin : a.in), 0, HAS_ISC ? a.Cin * 4 : 0, 0x00020000);
 
     // ---- per-thread staging constants: thread = (ci = wave, unit = lane), unit = rp * 16 + tu.
     // fp32 MFMA and vector-ALU instructions do NOT overlap on this hardware (tools/mfma_valu_coexec.hip: a loop of
@@ -117,14 +115,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
     // the DPP row; row r adds 32 bytes through the instruction's offset field
     const int hsrc = (2 * s_rp + (s_tu == 15 ? 1 : 0)) * 4;
     const int xlds = tid * 3;                                           // float4 index of this thread's 12 floats
-    int wvo[WJ];
-#pragma unroll
-    for (int jj = 0; jj < WJ; ++jj) {
-        const int idx = tid + jj * NTH;
-        const int ci_l = idx / (BN * 3);
-        const int rem = idx - ci_l * (BN * 3);
-        wvo[jj] = ci_l * g.CoutP * 48 + rem * 16;
-    }
+    const int wvo = lane * 16;                                          // weight DMA: this lane's 16 bytes inside a 1 KB chunk
 
     f32x4 acc[2][12];
 #pragma unroll
@@ -135,46 +126,52 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
     // staging registers: raw loads of the slab that is next to be transformed.  Rows 0 and 5 of the patch are read by pass 2
     // (phases 0, 5) only: they are loaded behind a wave-uniform branch in that pass and hold zeros before it (their
     // coefficients are 0 in passes 0 and 1 anyway).
-    f32x4 xv[6];
-    f32x4 xdummy[6];                                     // (ABL & 128 only: load destinations nobody waits for)
-    float xhl = 0.f, xsc = 1.f;                          // xhl: the wave's 48 halo samples, one per lane
-#pragma unroll
-    for (int r = 0; r < 6; r += 5) xv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // TWO sets: the loads of a slab are issued two slabs before its transform (set = slab parity), so that no wave ever sits
+    // in s_waitcnt vmcnt for activation data (measured gain over a one-slab distance: within noise - what the staging path
+    // costs is the ISSUE of its ~125 vector instructions per wave and slab, see above, not memory latency).
+    // (rows 0 and 5, which only the last pass reads, keep ONE set, xve: the register file has no room for a second one)
+    f32x4 xvs[2][4], xve[2];
+    float xhls[2] = {0.f, 0.f}, xscs[2] = {1.f, 1.f};     // xhls: the wave's 48 halo samples, one per lane
+    int pSs[2] = {0, 0};                                 // pass of the data held in each set
+    xve[0] = xve[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     // rows r0 .. r1-1 of the patch of slab (ps, ci0).  The loads of a slab are issued a few at a time BETWEEN the MFMA groups:
     // issued back to back by all eight waves they queue up in front of the CU's one address unit and every wave sits in
     // its load-issue phase at the same time (ablation: 240 of 750 us on the 256-channel layers).
-    // (`s2 ? +p2 : +p1`: the unary plus makes the conditional a VALUE - on two captured lvalues clang selects between their
-    // ADDRESSES, which keeps p1 / p2 / nb1 / nb2 in scratch memory and turns every buffer instruction into a waterfall loop)
-    auto issue_rows = [&](int ps, int ci0, int r0, int r1) __attribute__((always_inline)) {
+    auto issue_rows = [&](int set, int ps, int ci0, int r0, int r1) __attribute__((always_inline)) {
         if (ABL & 1) return;
-        const bool s2 = ci0 >= split;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(s2 ? +p2 : +p1), 0, s2 ? +nb2 : +nb1, 0x00020000);
-        const int so = (ABL & 64) ? 0 : (s2 ? (ci0 - split + wave) * cs2 : (ci0 + wave) * cs1) * 4;   // scalar: channel of this wave
+        const int so = (ABL & 64) ? 0 : (ci0 + wave) * cs1 * 4;       // scalar: channel of this wave
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             if (r < r0 || r >= r1) continue;
-            if (ABL & 128) xdummy[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, er[r], so, 0));
-            else xv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, er[r], so, 0));
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[r], so, 0));
+            if (r == 0) xve[0] = v;
+            else if (r == 5) xve[1] = v;
+            else xvs[set][r - 1] = v;
         }
     };
-    auto issue_halo = [&](int ci0) __attribute__((always_inline)) {
+    auto issue_halo = [&](int set, int ci0) __attribute__((always_inline)) {
         if (ABL & 1) return;
-        const bool s2 = ci0 >= split;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(s2 ? +p2 : +p1), 0, s2 ? +nb2 : +nb1, 0x00020000);
-        const int so = (ABL & 64) ? 0 : (s2 ? (ci0 - split + wave) * cs2 : (ci0 + wave) * cs1) * 4;
-        xhl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ehalo, so, 0));
+        const int so = (ABL & 64) ? 0 : (ci0 + wave) * cs1 * 4;
+        xhls[set] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ehalo, so, 0));
     };
-    auto issue_isc = [&](int ci0) __attribute__((always_inline)) {
-        if (HAS_ISC) xsc = a.in_scale[(long)b * a.Cin + ci0 + wave];          // one channel per wave: a scalar load
+    auto issue_isc = [&](int set, int ci0) __attribute__((always_inline)) {
+        if (HAS_ISC) xscs[set] = a.in_scale[(long)b * a.Cin + ci0 + wave];    // one channel per wave: a scalar load
     };
-    auto issue_act = [&](int ps, int ci0) __attribute__((always_inline)) {              // (prologue: everything at once)
-        issue_rows(ps, ci0, 1, 5);
-        if (ps == 2) {
-            issue_rows(ps, ci0, 0, 1);
-            issue_rows(ps, ci0, 5, 6);
-        }
-        issue_halo(ci0);
-        issue_isc(ci0);
+    auto issue_main = [&](int set, int ps, int ci0) __attribute__((always_inline)) {    // (prologue: rows 1-4 at once)
+        issue_rows(set, ps, ci0, 1, 5);
+        issue_halo(set, ci0);
+        issue_isc(set, ci0);
+        pSs[set] = ps;
+    };
+    // rows 0 and 5: pass 2 only.  Always issued - outside pass 2 with an out-of-range offset, which costs an instruction slot
+    // but no traffic: behind a branch hipcc cannot count the outstanding loads any more and waits for vmcnt(0) at the next
+    // transform, i.e. for the loads of the OTHER register set too.
+    auto issue_edge = [&](int ps, int ci0) __attribute__((always_inline)) {
+        if (ABL & 1) return;
+        const int so = (ABL & 64) ? 0 : (ci0 + wave) * cs1 * 4;
+        const unsigned edge = ps == 2 ? 0u : OOBH;
+        xve[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[0] | edge, so, 0));
+        xve[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[5] | edge, so, 0));
     };
     // lane i <- src of lane i-1 / i+1 inside its 16-lane row; the row's first / last lane keeps `old` (its own halo load).
     // Inline asm: hipcc 7.2 miscompiles __builtin_amdgcn_update_dpp on element 3 of a loaded vector (it reads element 0).
@@ -207,8 +204,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
         U[4] = e2 - 2.f * o2;
         U[5] = 4.f * E[1] + (E[5] - 5.f * E[3]);
     };
-    auto store_act = [&](int ps, f32x4* buf) __attribute__((always_inline)) {
+    auto store_act = [&](int set, f32x4* buf) __attribute__((always_inline)) {
         if (ABL & 8) return;
+        const int ps = pSs[set];
+        const f32x4 xv[6] = {xve[0], xvs[set][0], xvs[set][1], xvs[set][2], xvs[set][3], xve[1]};
+        const float xhl = xhls[set], xsc = xscs[set];
         const float k2 = fsel(ps, 0x40800000u, 0x3f800000u, 0x40a00000u);        // 4 1 5
         const float k1 = fsel(ps, 0x40800000u, 0x40000000u, 0x40800000u);        // 4 2 4
         const float k3 = fsel(ps, 0x3f800000u, 0x40000000u, 0x40a00000u);        // 1 2 5
@@ -247,12 +247,16 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
         buf[xlds + 1] = f32x4{Ua[4], Ua[5], Ub[0], Ub[1]};
         buf[xlds + 2] = f32x4{Ub[2], Ub[3], Ub[4], Ub[5]};
     };
+    // weight slab [8 ci][64 co][12] = 24 chunks of 1 KB (one wave instruction each), 3 per input channel; wave w moves chunks
+    // w, w + 8, w + 16: the chunk part of the address is scalar, the LDS image is the slab as it lies in memory
     auto dma_w = [&](int ps, int ci0, f32x4* buf, int j0, int j1) __attribute__((always_inline)) {
         if (ABL & 32) return;
-        const int so = ((ps * g.CinP + ci0) * g.CoutP + co0) * 48;     // bytes, scalar
 #pragma unroll
-        for (int jj = j0; jj < j1; ++jj)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(buf + XSZ + jj * NTH + wave * 64), 16, wvo[jj], so, 0, 0);
+        for (int jj = j0; jj < j1; ++jj) {
+            const int c = wave + 8 * jj;
+            const int so = ((ps * g.CinP + ci0 + c / 3) * g.CoutP + co0) * 48 + (c % 3) * 1024;     // bytes, scalar
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(buf + XSZ + c * 64), 16, wvo, so, 0, 0);
+        }
     };
     auto advance = [&](int& ps, int& ci0) __attribute__((always_inline)) {             // next slab, clamped at the last one
         int nc = ci0 + KC, np = ps;
@@ -270,35 +274,38 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
     const int aoff = XSZ + (lk * BN + cw * 16 + l15) * 3;
     const int boff = (lk * NU + uw * 32 + l15) * 3;
 
-    // ---- prologue: slabs 0 and 1 into buffers 0 and 1, loads of slab 2 in flight
-    int pA = 0, cA = 0;                          // slab whose activations are in the staging registers
-    issue_act(pA, cA);
-    dma_w(pA, cA, smem, 0, WJ);
-    store_act(pA, smem);
-    int pW = pA, cW = cA;                        // slab whose weights are DMA'd next
+    // ---- prologue: slabs 0 and 1 into buffers 0 and 1, loads of slabs 2 and 3 (edge rows: of slab 2) in flight
+    int pA = 0, cA = 0;                          // next slab to load rows 1-4 for
+    int pE = 0, cE = 0;                          // next slab to load rows 0 / 5 for (one slab behind pA in the loop)
+    int pW = 0, cW = 0;                          // next slab to DMA weights for
+    issue_main(0, pA, cA);
+    issue_edge(pE, cE);
     advance(pA, cA);
+    advance(pE, cE);
+    issue_main(1, pA, cA);
+    advance(pA, cA);
+    dma_w(pW, cW, smem, 0, WJ);
     advance(pW, cW);
-    issue_act(pA, cA);
     dma_w(pW, cW, smem + BUF, 0, WJ);
-    store_act(pA, smem + BUF);
-    advance(pA, cA);
     advance(pW, cW);
-    issue_act(pA, cA);                            // slab 2 (or a clamped copy of the last slab)
+    store_act(0, smem);
+    issue_edge(pE, cE);
+    advance(pE, cE);
+    issue_main(0, pA, cA);                        // slab 2 (or a clamped copy of the last slab)
+    advance(pA, cA);
+    store_act(1, smem + BUF);
+    issue_edge(pE, cE);                           // slab 2
+    advance(pE, cE);
+    issue_main(1, pA, cA);                        // slab 3
     __syncthreads();
 
-    f32x4 av[2], bv[2][2];
+    f32x4 av[1], bv[1][2];                        // (one operand set: the register file has no room for a prefetch set)
     av[0] = smem[aoff];
     bv[0][0] = smem[boff];
     bv[0][1] = smem[boff + 16 * 3];
 
     int rb = 0;                                   // ring slot of the slab being multiplied
     int pM = 0, cM = 0;                           // slab being multiplied (for the pass boundaries)
-    for (int j = 0; j < nslab; ++j) {
-        const int rn = rb == 2 ? 0 : rb + 1;      // slab j+1
-        const int rw = rn == 2 ? 0 : rn + 1;      // slab j+2: staged during this slab
-        const f32x4* Xs = smem + rb * BUF;
-        const f32x4* Xn = smem + rn * BUF;
-        f32x4* Xw = smem + rw * BUF;
 #define MFMA_GRP(c, pg)                                                                                               \
     if (!(ABL & 2)) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
         acc[0][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][0][i], acc[0][4 * (pg) + i], 0, 0, 0); \
@@ -312,72 +319,93 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
     }
 #define GROUP(cr, base, ks, pg, cm, pgm)       \
     READ_GRP(cr, base, ks, pg)                 \
+    __builtin_amdgcn_sched_barrier(0);         \
     MFMA_GRP(cm, pgm)                          \
     __builtin_amdgcn_sched_barrier(0);
-        // staging of slab j+2: transform + write of the activations held in the staging registers; then, spread over the
-        // MFMA groups, its weight DMA and the loads of slab j+3 into the freed registers (rows 0 / 5, which only pass 2
-        // reads, last)
-        store_act(pA, Xw);
-        advance(pA, cA);
-        issue_isc(cA);
-        __builtin_amdgcn_sched_barrier(0);
-        dma_w(pW, cW, Xw, 0, 1);
-        issue_rows(pA, cA, 1, 3);
-        GROUP(1, Xs, 0, 1, 0, 0)
-        dma_w(pW, cW, Xw, 1, 2);
-        issue_rows(pA, cA, 3, 5);
-        GROUP(0, Xs, 0, 2, 1, 1)
-        dma_w(pW, cW, Xw, 2, 3);
-        issue_halo(cA);
-        GROUP(1, Xs, 1, 0, 0, 2)
-        if (pA == 2) {                             // rows 0 and 5: phases 0 and 5 only
-            issue_rows(pA, cA, 0, 1);
-            issue_rows(pA, cA, 5, 6);
+    // One slab: staging of slab j+2 from register set SET (transform + write; its weights by DMA), then - spread over the
+    // MFMA groups - the loads of slab j+4 into the freed set and of rows 0 / 5 of slab j+3 (pass 2 only; one set), the MFMAs
+    // of slab j.
+#define SLAB(SET)                                                                                          \
+    {                                                                                                      \
+        const int rn = rb == 2 ? 0 : rb + 1;                                                               \
+        const int rw = rn == 2 ? 0 : rn + 1;                                                               \
+        const f32x4* Xs = smem + rb * BUF;                                                                 \
+        const f32x4* Xn = smem + rn * BUF;                                                                 \
+        f32x4* Xw = smem + rw * BUF;                                                                       \
+        store_act(SET, Xw);                                                                                \
+        advance(pA, cA);                                                                                   \
+        issue_isc(SET, cA);                                                                                \
+        pSs[SET] = pA;                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        issue_edge(pE, cE);                                                                                \
+        advance(pE, cE);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        dma_w(pW, cW, Xw, 0, WJ);                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        issue_rows(SET, pA, cA, 1, 3);                                                                     \
+        MFMA_GRP(0, 0)                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        issue_rows(SET, pA, cA, 3, 5);                                                                     \
+        GROUP(0, Xs, 0, 1, 0, 1)                                                                           \
+        issue_halo(SET, cA);                                                                               \
+        GROUP(0, Xs, 0, 2, 0, 2)                                                                           \
+        GROUP(0, Xs, 1, 0, 0, 0)                                                                           \
+        GROUP(0, Xs, 1, 1, 0, 1)                                                                           \
+        advance(pW, cW);                                                                                   \
+        GROUP(0, Xs, 1, 2, 0, 2)                                                                           \
+        READ_GRP(0, Xn, 0, 0)                                                                              \
+        /* slab j+2 complete (DMA + ds_write), slab j's buffer free.  Not __syncthreads(): its fence waits for vmcnt(0), */ \
+        /* i.e. for the loads of slab j+4 issued during this slab - the two-slab prefetch distance would be lost.  Memory */ \
+        /* operations complete in order, so the slab issues: rows 0 / 5 of slab j+3 (needed first), the three weight DMAs, */ \
+        /* then the 4 rows + halo of slab j+4: vmcnt(5) leaves exactly those five in flight.                               */ \
+        if (ABL & 16) {                                                                                    \
+        } else if (ABL & 1) {                                                                              \
+            __syncthreads();                                                                               \
+        } else {                                                                                           \
+            asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)");                                                 \
+            __builtin_amdgcn_s_barrier();                                                                  \
+        }                                                                                                  \
+        rb = rn;                                                                                           \
+    }
+    // pass boundary: carry the finished phases into the accumulators of the next pass (see the header)
+    auto carry = [&](int pm) __attribute__((always_inline)) {
+        if (pm == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    const f32x4 m1 = acc[i][p], m2 = acc[i][6 + p];
+                    acc[i][p] = 0.75f * m1 + 0.25f * m2;
+                    acc[i][6 + p] = 0.25f * m1 + 0.75f * m2;
+                }
+        } else if (pm == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    const f32x4 m3 = acc[i][p], m4 = acc[i][6 + p];
+                    acc[i][p] = m3 + m4;
+                    acc[i][6 + p] = 2.f * (m3 - m4);
+                }
         }
-        GROUP(0, Xs, 1, 1, 1, 0)
-        GROUP(1, Xs, 1, 2, 0, 1)
-        // last group: first operands of slab j+1 (its buffer was completed by the PREVIOUS barrier)
-        advance(pW, cW);
-        READ_GRP(0, Xn, 0, 0)
-        MFMA_GRP(1, 2)
-        if (ABL & 128) {                           // (timing only: the DMAs may not have landed)
-            asm volatile("s_waitcnt lgkmcnt(0)");
-            __builtin_amdgcn_s_barrier();
-        } else if (!(ABL & 16)) __syncthreads();   // slab j+2 complete (DMA + ds_write), slab j's buffer free
-        rb = rn;
-        // pass boundary: carry the finished phases into the accumulators of the next pass (see the header)
-        cM += KC;
+    };
+    // Two slabs per iteration (one per register set), straight line: the number of slabs per pass is even (Cin % 16 == 0,
+    // babe_conv2d_wino45_supported), so a pass can only end after the second one.  (With a branch between or inside the two
+    // slab bodies hipcc copied all 96 accumulator registers at every merge.)
+    for (int j = 0; j < nslab; j += 2) {
+        SLAB(0)
+        SLAB(1)
+        cM += 2 * KC;
         if (cM >= g.CinP) {
             cM = 0;
-            if (pM == 0) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int p = 0; p < 6; ++p) {
-                        const f32x4 m1 = acc[i][p], m2 = acc[i][6 + p];
-                        acc[i][p] = 0.75f * m1 + 0.25f * m2;
-                        acc[i][6 + p] = 0.25f * m1 + 0.75f * m2;
-                    }
-            } else if (pM == 1) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int p = 0; p < 6; ++p) {
-                        const f32x4 m3 = acc[i][p], m4 = acc[i][6 + p];
-                        acc[i][p] = m3 + m4;
-                        acc[i][6 + p] = 2.f * (m3 - m4);
-                    }
-            }
+            carry(pM);
             ++pM;
         }
     }
 #undef MFMA_GRP
 #undef READ_GRP
 #undef GROUP
-    if (ABL & 128) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) asm volatile("" ::"v"(xdummy[r]));
-    }
+#undef SLAB
 
     // ---- output: rows fa (from M_0) and fa + dil (from M_5), time transform A4^T; lane = (unit l15, channels 4 lk .. 4 lk + 3)
     const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
@@ -497,20 +525,34 @@ extern "C" int babe_conv2d_wino45_supported(const babe_conv_args* ap) {
     const babe_conv_args& a = *ap;
     auto al16 = [](const void* p) __attribute__((always_inline)) { return ((uintptr_t)p & 15) == 0; };
     if (a.KH != 5 || a.KW != 3 || a.T % 4 != 0 || a.T < 64 || a.dil < 1) return 0;   // (tiles are 64 time steps wide)
-    if (a.Cin < 8 || a.Cin % 8 != 0 || a.Cout < 33) return 0;   // (the channel part of a load address is a scalar offset,
-    // which the buffer range check does not cover: no padded input channels; few-channel convs run on conv_fewco / direct)
+    if (a.Cin < 16 || a.Cin % 16 != 0 || a.Cout < 33) return 0;   // (the channel part of a load address is a scalar offset,
+    // which the buffer range check does not cover: no padded input channels; an even number of 8-channel slabs per pass: the
+    // slab loop is unrolled by two; few-channel convs run on conv_fewco / direct)
     if (!al16(a.in) || a.in_bs % 4 || a.in_cs % 4) return 0;
-    if (a.in2 && (!al16(a.in2) || a.in2_bs % 4 || a.in2_cs % 4)) return 0;
+    if (a.in2) return 0;                                     // one source only (csrc/conv_wino45.hip, descriptors)
     if (!al16(a.out) || a.out_bs % 4 || a.out_cs % 4) return 0;
     if (a.res && (!al16(a.res) || a.res_bs % 4 || a.res_cs % 4)) return 0;
-    if (a.in2 && (a.cin_split % 8 != 0)) return 0;           // a slab never straddles the two sources
     const long lim = 0x3fffffffL / 4;                        // source views below 1 GiB per batch item (OOBH arithmetic)
-    const int split = a.in2 ? a.cin_split : a.Cin;
-    if ((long)split * a.in_cs >= lim) return 0;
-    if (a.in2 && (long)(a.Cin - split) * a.in2_cs >= lim) return 0;
+    if ((long)a.Cin * a.in_cs >= lim) return 0;
     if ((long)a.F * a.T >= lim) return 0;
     if (36L * ((a.Cin + 7) / 8 * 8) * ((a.Cout + 63) / 64 * 64) * 4 >= 0x7fffffffL) return 0;
     return 1;
+}
+
+/* 1 if the nested kernel is also the FASTER choice (what the dispatcher asks).  Tiles are 64 output channels x (4 row pairs of
+ * one residue class) x 64 time steps; the kernel is worth its 0.6x matrix work only while the tiles are reasonably full
+ * (measured 1.25-1.3x over conv_wino4p on full tiles): channels and time steps at least 7/8 used, row-pair slots at least
+ * 80 % (7 rows per class = 4 pairs, one half empty: 87.5 %; 10 rows per class = 5 pairs in 2 tiles: 62.5 %, left to
+ * conv_wino4p). */
+extern "C" int babe_conv2d_wino45_preferred(const babe_conv_args* ap) {
+    if (!babe_conv2d_wino45_supported(ap)) return 0;
+    const babe_conv_args& a = *ap;
+    const int n = (a.F + a.dil - 1) / a.dil;                 // rows per residue class
+    const int groups = ((n + 1) / 2 + 3) / 4;
+    const double u_rows = (double)n / (8.0 * groups);
+    const double u_t = (double)a.T / (64.0 * ((a.T + 63) / 64));
+    const double u_c = (double)a.Cout / (64.0 * ((a.Cout + 63) / 64));
+    return (u_rows >= 0.8 && u_t >= 0.875 && u_c >= 0.875) ? 1 : 0;
 }
 
 extern "C" int babe_conv2d_wino45(const babe_conv_args* ap, const float* w_wino45, void* stream) {

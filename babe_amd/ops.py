@@ -99,8 +99,10 @@ class PackedConv:
             check(L.babe_conv_pack_weights_wino45(ptr(w), ptr(self.bwd_wino45), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino45")
 
 
-def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=None, oscale=None, alpha=1.0, rbeta=0.0):
-    """out = alpha*conv(x[,x2]; W)*oscale + rbeta*res   (transpose=True: input-VJP weights)."""
+def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=None, oscale=None, alpha=1.0, rbeta=0.0,
+           force_nested=False):
+    """out = alpha*conv(x[,x2]; W)*oscale + rbeta*res   (transpose=True: input-VJP weights).
+    force_nested: take the nested-Winograd kernel whenever it CAN run the problem (tests), not only when it is preferred."""
     a = ConvArgs()
     B, C1, F, T = x.shape
     Cin = pc.Cout if transpose else pc.Cin
@@ -135,7 +137,8 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
         check(lib().babe_conv2d_bf16(C.byref(a), ptr(wq), pc.splits, stream()), "conv2d_bf16")
     elif FEWCO and getattr(pc, "w_raw", None) is not None and Cout <= 4 and lib().babe_conv2d_fewco_supported(C.byref(a)):
         check(lib().babe_conv2d_fewco(C.byref(a), ptr(pc.w_raw), int(transpose), stream()), "conv2d_fewco")
-    elif getattr(pc, "fwd_wino45", None) is not None and lib().babe_conv2d_wino45_supported(C.byref(a)):
+    elif getattr(pc, "fwd_wino45", None) is not None and (lib().babe_conv2d_wino45_supported(C.byref(a)) if force_nested
+                                                          else lib().babe_conv2d_wino45_preferred(C.byref(a))):
         check(lib().babe_conv2d_wino45(C.byref(a), ptr(pc.bwd_wino45 if transpose else pc.fwd_wino45), stream()), "conv2d_wino45")
     elif getattr(pc, "fwd_wino4", None) is not None and lib().babe_conv2d_wino4_supported(C.byref(a)):
         check(lib().babe_conv2d_wino4(C.byref(a), ptr(pc.bwd_wino4 if transpose else pc.fwd_wino4), stream()), "conv2d_wino4")

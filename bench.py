@@ -154,7 +154,7 @@ def spawn_ranks(n):
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 HBM_SLOTS = ["conv11", "gn_stats", "scale_gelu", "gn_bwd_partial", "gn_bwd_apply", "resample", "axpby", "cqt_band_analysis",
              "cqt_band_synthesis", "cqt_gather", "stft_fwd", "istft", "mag_stats", "sampler"]
-CONV_SLOTS = ["conv53_wino4", "conv53_wino2", "conv53_direct", "conv53_fewco", "conv11", "conv_bf16", "conv_bf16p"]
+CONV_SLOTS = ["conv53_wino45", "conv53_wino4", "conv53_wino2", "conv53_direct", "conv53_fewco", "conv11", "conv_bf16", "conv_bf16p"]
 
 
 def slot_table(prof, names, wall_s=None):
@@ -311,6 +311,8 @@ def main():
                  "bf16": "bf16 (bf16 MFMA, fp32 storage+accumulate)"}[a.precision]
         peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "f32" else 2500.0
         dom = "conv53_wino4" if a.precision == "f32" else "conv_bf16"
+        if a.precision == "f32" and timed is not None and timed["conv53_wino45"]["ms"] > timed["conv53_wino4"]["ms"]:
+            dom = "conv53_wino45"                        # the nested-Winograd kernel takes most of the (5,3) layers
         if a.precision == "bf16" and timed is not None and timed["conv_bf16p"]["launches"]:
             dom = "conv_bf16p"                           # the pipelined kernel takes the (5,3) layers of the bf16 build
         if timed is not None and timed[dom]["launches"]:
@@ -323,15 +325,19 @@ def main():
             tr = conv_traffic(a.precision)
             roof = {
                 "bound": "mfma",
-                "kernel": ("conv_wino4p_kernel: pipelined Winograd F(4,3)-along-time (5,3) conv, fp32 v_mfma_f32_32x32x2_f32, "
-                           "fwd + input-VJP launches of the UNet" if a.precision == "f32" else
+                "kernel": (("conv_wino45_kernel: nested Winograd F(2,5) along frequency x F(4,3) along time, fp32 "
+                            "v_mfma_f32_16x16x4_f32 (executes 0.3 of the algorithmic flops), fwd + input-VJP launches of the UNet; "
+                            "the layers it does not take run on conv_wino4p_kernel (all_conv_kernels)" if dom == "conv53_wino45" else
+                            "conv_wino4p_kernel: pipelined Winograd F(4,3)-along-time (5,3) conv, fp32 v_mfma_f32_32x32x2_f32, "
+                            "fwd + input-VJP launches of the UNet") if a.precision == "f32" else
                            "%s (v_mfma_f32_32x32x16_bf16; %s products per k-block)"
                            % ("conv_bf16p_kernel" if dom == "conv_bf16p" else "conv_bf16_kernel",
                               "3" if a.precision == "bf16x3" else "1")),
                 "achieved": round(r["flops"] / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(r["exec_flops"] / sec / 1e12 / peak, 4),
-                "frac_definition": "EXECUTED MFMA flops / duration / peak (F(4,3) executes 1/2 of the algorithmic "
-                                   "direct-convolution flops that `achieved` counts); algorithmic_frac = achieved / peak.  "
+                "frac_definition": "EXECUTED MFMA flops / duration / peak (F(4,3) executes 1/2, the nested F(2,5)xF(4,3) "
+                                   "kernel 3/10 of the algorithmic direct-convolution flops that `achieved` counts); "
+                                   "algorithmic_frac = achieved / peak.  "
                                    "`achieved` / `frac` / `avg_launch_us` are the kernel ALONE on the GPU (the `serial` "
                                    "block: all batch items on one stream, what the rocprofv3 summary under profiles/ "
                                    "reproduces) when that block exists; the same launches inside the two-lane timed region, "

@@ -88,9 +88,10 @@ long babe_conv_packed_size_wino4(int Cout, int Cin, int KH, int transpose_flip);
  * output instead of 7.5 (0.6 of the F(4,3) kernel's matrix work, 0.3 of the direct kernel's), fp32 MFMA, rounding error
  * about 3.4x the F(4,3) kernel's (2-3e-6 relative).  Replaces the same F.conv2d call (cqtdiff+.py:85) and its input-VJP.
  * w_wino45 from babe_conv_pack_weights_wino45: [3 passes][ceil8(Cin)][ceil64(Cout)][12].  Needs KH x KW = 5 x 3,
- * T % 4 == 0, T >= 64, Cin >= 8, Cout > 32, 16-byte aligned in/out/res rows, cin_split % 8 == 0, source views < 1 GiB. */
+ * T % 4 == 0, T >= 64, Cin % 16 == 0, Cout > 32, 16-byte aligned in/out/res rows, ONE source (no in2), views < 1 GiB. */
 int babe_conv2d_wino45(const babe_conv_args* a, const float* w_wino45, void* stream);
-int babe_conv2d_wino45_supported(const babe_conv_args* a);
+int babe_conv2d_wino45_supported(const babe_conv_args* a);   /* the kernel CAN run this problem */
+int babe_conv2d_wino45_preferred(const babe_conv_args* a);   /* ... and its tiles are full enough to beat the F(4,3) kernel */
 int babe_conv_pack_weights_wino45(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
                                   void* stream);
 long babe_conv_packed_size_wino45(int Cout, int Cin, int transpose_flip);

@@ -502,8 +502,8 @@ def test_gelu_one_exponential_form_is_within_fp32_roundoff_of_erf(ops):
     (1, 128, 0, 128, 40, 100, 4),      # ragged: T % 64 != 0, rows per class 10 -> 5 pairs -> 2 groups with empty slots
     (1, 96, 0, 96, 56, 64, 8),         # 96 channels (second 64-channel tile half empty), 7 rows per class (odd)
     (1, 256, 0, 256, 28, 64, 4),       # long reduction (32 slabs per pass)
-    (1, 64, 64, 128, 24, 192, 16),     # two-source input, dilation > rows per class / 2
-    (2, 40, 0, 72, 20, 68, 1),         # channel counts that are not multiples of 8 / 64
+    (1, 128, 0, 128, 24, 192, 16),     # dilation > rows per class / 2
+    (2, 48, 0, 72, 20, 68, 1),         # channel counts that are not multiples of 64
     (1, 128, 0, 64, 448, 64, 64),      # the benchmark's deepest geometry: 7 rows per class
 ])
 def test_conv2d_nested_winograd_vs_float64(ops, B, C1, C2, Cout, Fq, T, dil):
@@ -522,13 +522,13 @@ def test_conv2d_nested_winograd_vs_float64(ops, B, C1, C2, Cout, Fq, T, dil):
     x1, x2 = (xs[:, :C1].contiguous(), xs[:, C1:].contiguous()) if C2 else (xs, None)
     out = torch.empty(B, Cout, Fq, T, device="cuda")
     dispatch_counts(reset=True)
-    ops.conv2d(x1, pc, out, dil=dil, x2=x2)
+    ops.conv2d(x1, pc, out, dil=dil, x2=x2, force_nested=True)
     assert dispatch_counts()["conv53_wino45"] == 1
     e0 = rel(out, ref)
     res = torch.randn(B, Cout, Fq, T, generator=g)
     osc = torch.randn(B, Cout, generator=g)
     out2 = res.cuda().clone()
-    ops.conv2d(x1, pc, out2, dil=dil, x2=x2, res=out2, oscale=osc.cuda(), alpha=0.7, rbeta=0.3)
+    ops.conv2d(x1, pc, out2, dil=dil, x2=x2, res=out2, oscale=osc.cuda(), alpha=0.7, rbeta=0.3, force_nested=True)
     ref2 = 0.7 * ref * osc[:, :, None, None].double() + 0.3 * res.double()
     e1 = rel(out2, ref2)
     gy = torch.randn(B, Cout, Fq, T, generator=g)
@@ -538,7 +538,7 @@ def test_conv2d_nested_winograd_vs_float64(ops, B, C1, C2, Cout, Fq, T, dil):
     gref, = torch.autograd.grad((y * (gy * isc[:, :, None, None]).double()).sum(), xr)
     gx = torch.empty(B, Cin, Fq, T, device="cuda")
     dispatch_counts(reset=True)
-    ops.conv2d(gy.cuda(), pc, gx, dil=dil, transpose=True, in_scale=isc.cuda())
+    ops.conv2d(gy.cuda(), pc, gx, dil=dil, transpose=True, in_scale=isc.cuda(), force_nested=True)
     n45 = dispatch_counts()["conv53_wino45"]
     e2 = rel(gx, gref)
     print(f"nested Winograd Cin={Cin} Cout={Cout} F={Fq} T={T} dil={dil}: fwd {e0:.2e}, epilogue {e1:.2e}, vjp {e2:.2e} (wino45 launches {n45})")

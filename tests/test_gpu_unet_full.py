@@ -69,7 +69,7 @@ def test_full_width_L46046_vs_reference_golden():
     assert ey < TOL_FWD and eg < TOL_VJP
     # frame counts 512 ... 8: the T=8 layers (enc6, the two pyramid convs that run at 8 frames, mid, dec6 = 23 convs) are
     # below F(4,3)'s 16-frame minimum and run the direct kernel; everything else must be on the F(4,3) kernel
-    assert cf["conv53_wino4"] + cf["conv53_direct"] == 82 and cf["conv53_direct"] <= 23 and cf["conv53_wino2"] == 0, cf
+    assert cf["conv53_wino4"] + cf["conv53_wino45"] + cf["conv53_direct"] == 82 and cf["conv53_direct"] <= 23 and cf["conv53_wino2"] == 0, cf
     assert cf["conv_bf16"] == 0 and cb["conv_bf16"] == 0
 
 
@@ -81,11 +81,15 @@ def test_full_width_L368368_vs_reference_golden_all_wino4():
     ey, eg = rel(y, g["y"]), rel(gx, g["gx"])
     print(f"full width L={L}: fwd rel {ey:.2e}, vjp rel {eg:.2e}; dispatch fwd {cf} vjp {cb}")
     assert ey < TOL_FWD and eg < TOL_VJP
-    # forward: 75 dilated ResnetBlock convs + 7 pyramid projections, all on conv_wino4_kernel
-    assert cf["conv53_wino4"] == 82 and cf["conv53_wino2"] == 0 and cf["conv53_direct"] == 0, cf
+    # forward: 75 dilated ResnetBlock convs + 7 pyramid projections, all on the Winograd kernels: the nested
+    # F(2,5) x F(4,3) kernel where its tiles are full (64 / 128 / 256 channels), conv_wino4p elsewhere (96 channels, the
+    # 2-channel pyramid inputs, the high dilations of the 320- and 384-bin levels)
+    assert cf["conv53_wino4"] + cf["conv53_wino45"] == 82 and cf["conv53_wino45"] >= 40, cf
+    assert cf["conv53_wino2"] == 0 and cf["conv53_direct"] == 0, cf
     # VJP: the 75 dilated convs on F(4,3); the 7 pyramid projections transposed have 2 output channels and run on the
     # vector-ALU kernel (csrc/conv_fewco.hip)
-    assert cb["conv53_wino4"] == 75 and cb["conv53_fewco"] == 7 and cb["conv53_wino2"] == 0 and cb["conv53_direct"] == 0, cb
+    assert cb["conv53_wino4"] + cb["conv53_wino45"] == 75 and cb["conv53_wino45"] >= 40, cb
+    assert cb["conv53_fewco"] == 7 and cb["conv53_wino2"] == 0 and cb["conv53_direct"] == 0, cb
     assert cf["conv_bf16"] == 0 and cb["conv_bf16"] == 0
 
 
@@ -107,7 +111,7 @@ def test_full_width_two_lanes_equal_single_stream_bit_exact():
     assert torch.equal(y2, y1) and torch.equal(g2, g1)
     assert torch.equal(y1[0], y1[1]) and torch.equal(g1[0], g1[1])
     assert rel(y1[:1], g["y"]) < TOL_FWD and rel(g1[:1], g["gx"]) < TOL_VJP
-    assert cf["conv53_wino4"] == 82 and cb["conv53_wino4"] == 75
+    assert cf["conv53_wino4"] + cf["conv53_wino45"] == 82 and cb["conv53_wino4"] + cb["conv53_wino45"] == 75
 
 
 # ---- reduced-precision builds at FULL width.  The reference is fp32-only; 'bf16x3' (hi/lo split, three
@@ -130,7 +134,7 @@ def test_full_width_reduced_precision_vs_reference_golden(precision, L):
     # the (5,3) layers must have run on the bf16 MFMA kernels (pipelined kernel for plain bf16), not on an fp32 fallback
     n_bf16 = cf["conv_bf16"] + cf["conv_bf16p"]
     # (the 7 two-input-channel pyramid projections stay on the exact fp32 kernels in every mode: ops.PackedConv)
-    assert n_bf16 >= 75 and cf["conv53_wino4"] + cf["conv53_direct"] <= 7 and cf["conv53_wino2"] == 0, cf
+    assert n_bf16 >= 75 and cf["conv53_wino4"] + cf["conv53_direct"] <= 7 and cf["conv53_wino2"] == 0 and cf["conv53_wino45"] == 0, cf
     assert cb["conv_bf16"] + cb["conv_bf16p"] >= 75 and cb["conv53_wino4"] == 0, cb
     if precision == "bf16" and L == 368368:
         assert cf["conv_bf16p"] >= 75 and cb["conv_bf16p"] >= 75, (cf, cb)     # every dilated layer on conv_bf16p_kernel
@@ -200,7 +204,7 @@ def test_full_width_blind_sampler_two_lanes_vs_reference_golden():
     # T = 3, order 2: 5 score evaluations per lane = 5 forwards + 5 VJPs per lane; frames 512..8, so the layers with >= 16
     # frames are on the F(4,3) kernel and only the 8-frame ones on the direct kernel
     print("full-width sampler dispatch:", {k: v for k, v in cnt.items() if v})
-    assert cnt["conv53_wino4"] >= 2 * 5 * (59 + 52) and cnt["conv53_wino2"] == 0 and cnt["conv_bf16"] == 0, cnt
+    assert cnt["conv53_wino4"] + cnt["conv53_wino45"] >= 2 * 5 * (59 + 52) and cnt["conv53_wino2"] == 0 and cnt["conv_bf16"] == 0, cnt
     assert cnt["conv53_direct"] <= 2 * 5 * (23 + 23), cnt
 
 
