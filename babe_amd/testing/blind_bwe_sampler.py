@@ -302,7 +302,8 @@ class BlindSampler:
 
     def _use_lanes(self, B, y, rid, filter_params):
         return (self.LANES > 1 and B >= 2 and y is not None and not rid and self.batch_semantics == "per_clip" and
-                getattr(self.model, "supports_lanes", False) and self.ar_mask is None and self.dc is None and
+                getattr(self.model, "supports_lanes", False) and getattr(self.model, "concurrent_lanes_ok", True) and
+                self.ar_mask is None and self.dc is None and
                 self.fir_taps is None and filter_params.shape[0] == B)
 
     def _sample_lanes(self, x, y, specY, filter_params, blind, snoise, t, gamma):

@@ -56,6 +56,10 @@ class ResidualNet:
 
     supports_lanes = True
 
+    @property
+    def concurrent_lanes_ok(self):
+        return getattr(self.inner, "concurrent_lanes_ok", True)
+
     def fwd_nograd(self, x, cn, lane=None):
         self.k = float(torch.exp(4 * cn[0, 0])) / self.sd          # (one sigma per call; same for every lane of a step)
         kw = {} if lane is None else {"lane": lane}

@@ -151,6 +151,10 @@ class ResidualNet:
 
     supports_lanes = True
 
+    @property
+    def concurrent_lanes_ok(self):
+        return getattr(self.inner, "concurrent_lanes_ok", True)
+
     def fwd_nograd(self, x, cn, lane=None):
         self.k = float(torch.exp(4 * cn[0, 0])) / self.sd
         kw = {} if lane is None else {"lane": lane}
@@ -230,4 +234,7 @@ def test_full_width_bf16_sampler_B4_per_clip_vs_fp32_reference_runs():
         e_rms, e_rel = rms_err(x[b:b + 1], ref), rel(x[b:b + 1], ref)
         print(f"full-width bf16 sampler clip {b}: RMS err {e_rms:.2e}, rel {e_rel:.2e}")
         assert e_rms < 5e-3
-    assert rel(x[0], x[2]) < 1e-6 and rel(x[1], x[3]) < 1e-6               # per-clip semantics: same clip, same result
+    # per-clip semantics: same clip, same result.  (bf16 networks run their clips on ONE stream: see the known issue at
+    # Unet_CQT_oct_with_attention.concurrent_lanes_ok.)
+    assert not smp._use_lanes(4, y, False, fp.reshape(4, 2, -1))
+    assert rel(x[0], x[2]) < 1e-6 and rel(x[1], x[3]) < 1e-6
