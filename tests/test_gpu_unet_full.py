@@ -203,7 +203,14 @@ def test_full_width_blind_sampler_two_lanes_vs_reference_golden():
     for b in range(2):
         e_rms, e_rel = rms_err(x[b:b + 1], s[f"x{b}"]), rel(x[b:b + 1], s[f"x{b}"])
         print(f"full-width sampler clip {b}: RMS err {e_rms:.2e}, rel {e_rel:.2e}; filter {fp[b].tolist()} vs {s[f'fp{b}'].tolist()}")
-        assert e_rms < 1e-3 and e_rel < 5e-3
+        # clip 1 agrees to 2e-5.  Clip 0 carries a documented discontinuity of the REFERENCE algorithm: in its second score
+        # evaluation the fitted fc[2] comes out at 409.1317 Hz in the reference and 409.1301 Hz here (difference 0.0016 Hz after
+        # 100 GD iterations, the fit itself matches to 0.003 Hz on the reference's own inputs: tools/fit_trajectory_probe.py),
+        # and the frequency of STFT bin 38, 409.1309 Hz, lies between the two - the mask `f >= fc` of design_filter
+        # (utils/blind_bwe_utils.py:96-111) puts that bin in different filter segments, the guidance term of that evaluation
+        # differs by 4 % (tools/eval_probe.py: every other evaluation of the run agrees to 4e-5) and the output by 2.9e-3
+        # relative = 2.5e-4 RMS, inside the 1e-3 RMS bar.
+        assert e_rms < 1e-3 and e_rel < (5e-3 if b == 0 else 1e-4)
         assert torch.allclose(fp[b, 0].cpu(), s[f"fp{b}"][0], rtol=1e-2) and torch.allclose(fp[b, 1].cpu(), s[f"fp{b}"][1], atol=1.0)
     # T = 3, order 2: 5 score evaluations per lane = 5 forwards + 5 VJPs per lane; frames 512..8, so the layers with >= 16
     # frames are on the F(4,3) kernel and only the 8-frame ones on the direct kernel
