@@ -9,6 +9,13 @@ OUT = os.path.join(HERE, "libbabe_hip.so")
 SOURCES = ["misc.hip", "conv.hip", "conv11p.hip", "conv_fewco.hip", "conv_bf16.hip", "conv_bf16p.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4p.hip", "conv_wino45.hip", "norm.hip", "resample.hip", "cqt.hip", "stft.hip", "sampler.hip", "denoiser.hip"]
 
 
+# per-source extra flags.  conv_wino45: hipcc's SLP vectoriser packs the input-transform arithmetic into v_pk_* instructions
+# and pays for it with ~35 register moves per K-slab; next to fp32 MFMAs every vector instruction costs matrix-pipe time
+# (tools/mfma_valu_coexec.hip: a v_pk_fma_f32 costs 1.6x a v_fma_f32, a v_mov as much as a v_fma): 207 instead of 245 vector
+# instructions per two slabs without it
+EXTRA_FLAGS = {"conv_wino45.hip": ["-fno-slp-vectorize"]}
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
@@ -51,7 +58,7 @@ def _build_locked(force, verbose):
         if (not force) and os.path.exists(o) and os.path.getmtime(o) > max([os.path.getmtime(p), hdr_mtime]):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", p, "-o", o,
-               "-Wno-unused-result"]
+               "-Wno-unused-result"] + EXTRA_FLAGS.get(src, [])
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
