@@ -121,11 +121,11 @@ def cpu_baseline():
     return out
 
 
-PMC_TRAFFIC_FILE = "r02_conv_traffic.json"
+PMC_TRAFFIC_FILE = "r03_conv_traffic.json"
 
 
 def conv_traffic(precision):
-    """HBM-side bytes per conv_wino4 launch from the committed PMC passes (rocprofv3 cannot run inside the bench; the
+    """HBM-side bytes per launch of the dominant conv kernel (conv_wino45_kernel) from the committed PMC passes (rocprofv3 cannot run inside the bench; the
     passes are separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this command, profiles/README.md)."""
     path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     if precision != "f32" or not os.path.exists(path):
