@@ -49,8 +49,16 @@ struct Wino45Geom {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr unsigned OOBH = 0xC0000000u;     // invalid offsets start here: +-(a source view < 1 GiB) stays >= 2^31
 
+// Optional register cap (-DBABE_W45_NUM_VGPR=112; the attribute counts in halves of the unified file on gfx90a+, so 112 means
+// 224 registers per wave).  Idea: two waves of this kernel per SIMD would then leave 64 of the SIMD's 512 registers, room
+// for one wave of an element-wise kernel (GroupNorm, GELU, axpby, resample: 8..62 VGPRs) of the sampler's other lane.
+// Measured (round 3, same box, same session): 25 spilled registers, kernels 1 % slower, headline 1.636 vs 1.640 - the
+// two-lane overlap is not limited by registers.  Default: no cap (248 / 243 registers, no spills).
+#ifndef BABE_W45_NUM_VGPR
+#define BABE_W45_NUM_VGPR 128
+#endif
 template <bool HAS_ISC>
-__global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, Wino45Geom g, const float* __restrict__ wq) {
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM_VGPR))) void conv_wino45_kernel(babe_conv_args a, Wino45Geom g, const float* __restrict__ wq) {
 #if __HIP_DEVICE_COMPILE__
     constexpr int NTH = 512, KC = 8, BN = 64, NU = 64;
     constexpr int XSZ = KC * NU * 3;                    // float4 per activation image (12 floats per (ci, unit))
@@ -126,13 +134,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
     // staging registers: raw loads of the slab that is next to be transformed.  Rows 0 and 5 of the patch are read by pass 2
     // (phases 0, 5) only: they are loaded behind a wave-uniform branch in that pass and hold zeros before it (their
     // coefficients are 0 in passes 0 and 1 anyway).
-    // TWO sets: the loads of a slab are issued two slabs before its transform (set = slab parity), so that no wave ever sits
-    // in s_waitcnt vmcnt for activation data (measured gain over a one-slab distance: within noise - what the staging path
-    // costs is the ISSUE of its ~125 vector instructions per wave and slab, see above, not memory latency).
-    // (rows 0 and 5, which only the last pass reads, keep ONE set, xve: the register file has no room for a second one)
-    f32x4 xvs[2][4], xve[2];
-    float xhls[2] = {0.f, 0.f}, xscs[2] = {1.f, 1.f};     // xhls: the wave's 48 halo samples, one per lane
-    int pSs[2] = {0, 0};                                 // pass of the data held in each set
+    // ONE set, loaded one slab before its transform.  (A second set - loads issued two slabs ahead - measured within noise:
+    // what the staging path costs is the ISSUE of its ~125 vector instructions per wave and slab, not memory latency; and
+    // its 17 registers put the kernel at 256 VGPRs with 10 spilled.)
+    f32x4 xvs[1][4], xve[2];
+    float xhls[1] = {0.f}, xscs[1] = {1.f};               // xhls: the wave's 48 halo samples, one per lane
+    int pSs[1] = {0};                                    // pass of the data held in the set
     xve[0] = xve[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     // rows r0 .. r1-1 of the patch of slab (ps, ci0).  The loads of a slab are issued a few at a time BETWEEN the MFMA groups:
     // issued back to back by all eight waves they queue up in front of the CU's one address unit and every wave sits in
@@ -274,29 +281,23 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
     const int aoff = XSZ + (lk * BN + cw * 16 + l15) * 3;
     const int boff = (lk * NU + uw * 32 + l15) * 3;
 
-    // ---- prologue: slabs 0 and 1 into buffers 0 and 1, loads of slabs 2 and 3 (edge rows: of slab 2) in flight
-    int pA = 0, cA = 0;                          // next slab to load rows 1-4 for
-    int pE = 0, cE = 0;                          // next slab to load rows 0 / 5 for (one slab behind pA in the loop)
+    // ---- prologue: slabs 0 and 1 into buffers 0 and 1, loads of slab 2 in flight
+    int pA = 0, cA = 0;                          // next slab to load for
     int pW = 0, cW = 0;                          // next slab to DMA weights for
+    issue_edge(pA, cA);
     issue_main(0, pA, cA);
-    issue_edge(pE, cE);
-    advance(pA, cA);
-    advance(pE, cE);
-    issue_main(1, pA, cA);
-    advance(pA, cA);
     dma_w(pW, cW, smem, 0, WJ);
     advance(pW, cW);
     dma_w(pW, cW, smem + BUF, 0, WJ);
     advance(pW, cW);
     store_act(0, smem);
-    issue_edge(pE, cE);
-    advance(pE, cE);
-    issue_main(0, pA, cA);                        // slab 2 (or a clamped copy of the last slab)
     advance(pA, cA);
-    store_act(1, smem + BUF);
-    issue_edge(pE, cE);                           // slab 2
-    advance(pE, cE);
-    issue_main(1, pA, cA);                        // slab 3
+    issue_edge(pA, cA);
+    issue_main(0, pA, cA);                        // slab 1 (or a clamped copy of the last slab)
+    store_act(0, smem + BUF);
+    advance(pA, cA);
+    issue_edge(pA, cA);
+    issue_main(0, pA, cA);                        // slab 2
     __syncthreads();
 
     f32x4 av[1], bv[1][2];                        // (one operand set: the register file has no room for a prefetch set)
@@ -322,9 +323,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
     __builtin_amdgcn_sched_barrier(0);         \
     MFMA_GRP(cm, pgm)                          \
     __builtin_amdgcn_sched_barrier(0);
-    // One slab: staging of slab j+2 from register set SET (transform + write; its weights by DMA), then - spread over the
-    // MFMA groups - the loads of slab j+4 into the freed set and of rows 0 / 5 of slab j+3 (pass 2 only; one set), the MFMAs
-    // of slab j.
+    // One slab: staging of slab j+2 from the register set (transform + write; its weights by DMA), then - spread over the
+    // MFMA groups - the loads of slab j+3 into the freed set, the MFMAs of slab j.
 #define SLAB(SET)                                                                                          \
     {                                                                                                      \
         const int rn = rb == 2 ? 0 : rb + 1;                                                               \
@@ -337,8 +337,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
         issue_isc(SET, cA);                                                                                \
         pSs[SET] = pA;                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        issue_edge(pE, cE);                                                                                \
-        advance(pE, cE);                                                                                   \
+        issue_edge(pA, cA);                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         dma_w(pW, cW, Xw, 0, WJ);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
@@ -355,9 +354,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
         GROUP(0, Xs, 1, 2, 0, 2)                                                                           \
         READ_GRP(0, Xn, 0, 0)                                                                              \
         /* slab j+2 complete (DMA + ds_write), slab j's buffer free.  Not __syncthreads(): its fence waits for vmcnt(0), */ \
-        /* i.e. for the loads of slab j+4 issued during this slab - the two-slab prefetch distance would be lost.  Memory */ \
-        /* operations complete in order, so the slab issues: rows 0 / 5 of slab j+3 (needed first), the three weight DMAs, */ \
-        /* then the 4 rows + halo of slab j+4: vmcnt(5) leaves exactly those five in flight.                               */ \
+        /* i.e. for the loads of slab j+3 issued during this slab.  Memory operations complete in order, so the slab      */ \
+        /* issues: rows 0 / 5 of slab j+3, the three weight DMAs, then its 4 rows + halo: vmcnt(5) leaves those five in    */ \
+        /* flight.                                                                                                         */ \
         if (ABL & 16) {                                                                                    \
         } else if (ABL & 1) {                                                                              \
             __syncthreads();                                                                               \
@@ -389,13 +388,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino45_kernel(babe_conv_args a, W
                 }
         }
     };
-    // Two slabs per iteration (one per register set), straight line: the number of slabs per pass is even (Cin % 16 == 0,
-    // babe_conv2d_wino45_supported), so a pass can only end after the second one.  (With a branch between or inside the two
-    // slab bodies hipcc copied all 96 accumulator registers at every merge.)
-    for (int j = 0; j < nslab; j += 2) {
+    for (int j = 0; j < nslab; ++j) {
         SLAB(0)
-        SLAB(1)
-        cM += 2 * KC;
+        cM += KC;
         if (cM >= g.CinP) {
             cM = 0;
             carry(pM);
