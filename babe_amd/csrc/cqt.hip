@@ -12,45 +12,57 @@ namespace {
 // A workgroup of 256 threads owns 4096 complex points of ONE octave: 4096/T bands of T points each (64 bands when
 // T <= 64), so every workgroup of the launch has the same amount of work whatever the octave - the round-1 kernel gave a
 // 512-thread workgroup to every band, and 192 of the 448 bands used an eighth of it.  A band of T = R0 * TB points
-// (R0 = min(16, T)) is transformed by TB threads in ceil(log16 T) passes: each thread gathers the R0 inputs of its
-// butterflies from LDS (stride T/R), multiplies by the inter-pass twiddles (table exp(-2 pi i q/4096) copied to LDS once
-// per workgroup), runs the radix-R DFT in registers (R = 16 as 4 x 4, 8 as 4 x 2) and scatters the results autosorted, so
-// input and output are both in natural order and nothing is bit-reversed.  One LDS buffer: read - barrier - write - barrier.
+// (R0 = min(16, T)) is transformed by TB threads in ceil(log16 T) passes: a thread holds the R0 inputs of its butterflies
+// in registers (stride T/R), multiplies by the inter-pass twiddles (exp(-2 pi i q/4096): four table entries per butterfly
+// from global memory, the other eleven as products), runs the radix-R DFT in registers (R = 16 as 4 x 4, 8 as 4 x 2) and
+// scatters the results autosorted through LDS to the next pass, so input and output are both in natural order and nothing
+// is bit-reversed.  One LDS buffer between passes: write - barrier - read - barrier.
 // Element i of the workgroup's image lives at i + (i >> 4) (the first pass writes with stride 16: without the pad all lanes
 // of a wave hit two banks).
 #define CQ_AT(i) ((i) + ((i) >> 4))
 constexpr int CQ_PTS = 4096;                           // points per workgroup
 constexpr int CQ_LDS = CQ_PTS + (CQ_PTS >> 4);         // float2 elements
 
-__device__ __forceinline__ float2 cq_mul(float2 x, float2 w) { return make_float2(x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x); }
-__device__ __forceinline__ float2 cq_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 cq_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// Complex values are 2-vectors (register pairs): hipcc turns the arithmetic below into packed fp32 instructions
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) plus some moves of the halves.  (Round 3 tried the same operations as inline
+// asm with op_sel / neg modifiers instead of the moves: 921 -> 571 vector instructions per 4096-point band and NO change in
+// the kernel time - the kernel is bound by its memory traffic, not by the vector ALU; dropped.)
+typedef float f2 __attribute__((ext_vector_type(2)));
+// a + (S i) b
+template <int S>
+__device__ __forceinline__ f2 cq_add_i(f2 a, f2 b) {
+    return S > 0 ? f2{a.x - b.y, a.y + b.x} : f2{a.x + b.y, a.y - b.x};
+}
+// x * w (CONJ: x * conj(w))
+template <bool CONJ>
+__device__ __forceinline__ f2 cq_mul(f2 x, f2 w) {
+    return CONJ ? f2{x.x * w.x + x.y * w.y, x.y * w.x - x.x * w.y} : f2{x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x};
+}
 
 // 4-point DFT, sign S (exp(S 2 pi i nk/4)), in place, natural order
 template <int S>
-__device__ __forceinline__ void cq_fft4(float2& x0, float2& x1, float2& x2, float2& x3) {
-    const float2 a0 = cq_add(x0, x2), a1 = cq_sub(x0, x2), a2 = cq_add(x1, x3), d = cq_sub(x1, x3);
-    const float2 a3 = S > 0 ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);        // (S i) * d
-    x0 = cq_add(a0, a2);
-    x1 = cq_add(a1, a3);
-    x2 = cq_sub(a0, a2);
-    x3 = cq_sub(a1, a3);
+__device__ __forceinline__ void cq_fft4(f2& x0, f2& x1, f2& x2, f2& x3) {
+    const f2 a0 = x0 + x2, a1 = x0 - x2, a2 = x1 + x3, d = x1 - x3;
+    x0 = a0 + a2;
+    x2 = a0 - a2;
+    x1 = cq_add_i<S>(a1, d);
+    x3 = cq_add_i<-S>(a1, d);
 }
 // R-point DFT of v[0..R-1] in registers, R in {2, 4, 8, 16}.  R = 4 * R2: v[R2*k1 + k2] receives X[k1 + 4*k2]; the
 // caller un-permutes with cq_perm<R>(r) when it stores.
 template <int R, int S>
-__device__ __forceinline__ void cq_fft(float2* v) {
+__device__ __forceinline__ void cq_fft(f2* v) {
     if constexpr (R == 2) {
-        const float2 a = v[0], b = v[1];
-        v[0] = cq_add(a, b);
-        v[1] = cq_sub(a, b);
+        const f2 a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
     } else if constexpr (R == 4) {
         cq_fft4<S>(v[0], v[1], v[2], v[3]);
     } else {
         constexpr int R2 = R / 4;
 #pragma unroll
         for (int n2 = 0; n2 < R2; ++n2) cq_fft4<S>(v[n2], v[R2 + n2], v[2 * R2 + n2], v[3 * R2 + n2]);
-        // twiddles W_R^(n2*k1), W_R = exp(S 2 pi i / R)
+        // twiddles W_R^(n2*k1), W_R = exp(S 2 pi i / R): the table holds exp(+2 pi i m/16), S < 0 multiplies by the conjugate
         constexpr float C16[10] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.f,
                                    -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.f,
                                    -0.92387953251128674f};
@@ -63,7 +75,8 @@ __device__ __forceinline__ void cq_fft(float2* v) {
             for (int n2 = 1; n2 < R2; ++n2) {
                 constexpr int unit = 16 / R;                    // index into the 16th-root table
                 const int m = n2 * k1 * unit;                   // <= 9
-                v[R2 * k1 + n2] = cq_mul(v[R2 * k1 + n2], make_float2(C16[m], S > 0 ? S16[m] : -S16[m]));
+                if (m == 4) v[R2 * k1 + n2] = cq_add_i<S>(f2{0.f, 0.f}, v[R2 * k1 + n2]);       // (S i) x
+                else v[R2 * k1 + n2] = cq_mul<(S < 0)>(v[R2 * k1 + n2], f2{C16[m], S16[m]});
             }
 #pragma unroll
         for (int k1 = 0; k1 < 4; ++k1) cq_fft<R2, S>(v + R2 * k1);
@@ -79,160 +92,227 @@ __device__ __forceinline__ constexpr int cq_perm(int r) {       // register r of
     }
 }
 
-// One Stockham pass of radix R over every band of the workgroup.  LT = log2 T, Ns = product of the earlier radices.
-// The band of this thread starts at element `base` of the image; u = its index among the band's TB threads.
-template <int LT, int R, int NSL, int S>
-__device__ __forceinline__ void cq_pass(float2* a, const float2* twl, int base, int u, bool active) {
-    constexpr int N = 1 << LT;
-    constexpr int R0 = N < 16 ? N : 16;
-    constexpr int TB = N / R0;
-    constexpr int CNT = R0 / R;                        // butterflies per thread in this pass
-    constexpr int NR = N / R;
-    constexpr int Ns = 1 << NSL;
-    float2 v[CNT][R];
-    if (active) {
-#pragma unroll
-        for (int c = 0; c < CNT; ++c) {
-            const int j = u + c * TB;
-#pragma unroll
-            for (int t = 0; t < R; ++t) v[c][t] = a[CQ_AT(base + j + t * NR)];
-            if constexpr (NSL > 0) {
-                const int k = j & (Ns - 1);
-                constexpr int stride = 4096 / (Ns * R);
-#pragma unroll
-                for (int t = 1; t < R; ++t) {
-                    const int q = k * t * stride;       // < 4096
-                    float2 w = twl[q & 2047];
-                    if (q & 2048) w = make_float2(-w.x, -w.y);
-                    if (S > 0) w.y = -w.y;
-                    v[c][t] = cq_mul(v[c][t], w);
-                }
-            }
-            cq_fft<R, S>(v[c]);
-        }
-    }
-    __syncthreads();
-    if (active) {
-#pragma unroll
-        for (int c = 0; c < CNT; ++c) {
-            const int j = u + c * TB;
-            const int d = ((j >> NSL) << (NSL + __builtin_ctz(R))) + (j & (Ns - 1));
-#pragma unroll
-            for (int r = 0; r < R; ++r) a[CQ_AT(base + d + cq_perm<R>(r) * Ns)] = v[c][r];
-        }
-    }
-    __syncthreads();
+// ---- pass plan of a T = 2^LT point band: radices 16,16,16 / 16,16,8 / 16,16,4 / 16,8,4 / 16,16 / 16,8 / 16,4 / 16,2 / 16 / 8 / 4
+__host__ __device__ constexpr int cq_npass(int LT) { return LT >= 9 ? 3 : (LT >= 5 ? 2 : 1); }
+__host__ __device__ constexpr int cq_radix(int LT, int p) {
+    if (LT <= 3) return 1 << LT;
+    if (p == 0) return 16;
+    if (LT >= 10) return p == 1 ? 16 : (1 << (LT - 8));
+    if (LT == 9) return p == 1 ? 8 : 4;
+    return 1 << (LT - 4);                       // LT 5..8, p == 1
 }
-// the whole transform of a T = 2^LT point band held at a[base ...]: radices 16,16,16 / 16,16,8 / 16,16,4 / 16,8,4 / 16,16 /
-// 16,8 / 16,4 / 16,2 / 16 / 8
+__host__ __device__ constexpr int cq_log2(int v) { return v <= 1 ? 0 : 1 + cq_log2(v >> 1); }
+__host__ __device__ constexpr int cq_nsl(int LT, int p) { return p == 0 ? 0 : cq_nsl(LT, p - 1) + cq_log2(cq_radix(LT, p - 1)); }
+
+// table entry exp(S' 2 pi i q / 4096), q in [0, 2048); the table (global memory, 16 KB: L1 / L2 resident) holds
+// exp(-2 pi i q / 4096) for q < 2048
+// (callers: q = k t with k < 4096 / (Ns R) * Ns and t in {1, 2, 4, 8} <= R / 2: always below 2048, no sign fold)
+__device__ __forceinline__ f2 cq_tw(const f2* __restrict__ tw, int q) { return tw[q]; }
+
+// Stockham pass P of a band, data in REGISTERS between the butterflies and LDS only between passes:
+//   butterfly c of thread u: j = u + c*TB; inputs t = 0..R-1 are elements j + t*N/R of the previous stage, multiplied by
+//   W^(k t), k = j mod Ns (Ns = product of the earlier radices); outputs r land at d + cq_perm(r)*Ns,
+//   d = (j / Ns) * Ns * R + k (autosort: natural order in and out).
+// v[] holds the R0 = min(16, T) values of the thread: as [CNT][R] for a pass of radix R (CNT = R0 / R butterflies).
+template <int LT, int P>
+struct CqPass {
+    static constexpr int N = 1 << LT;
+    static constexpr int R0 = N < 16 ? N : 16;
+    static constexpr int TB = N / R0;
+    static constexpr int R = cq_radix(LT, P);
+    static constexpr int LR = cq_log2(R);
+    static constexpr int CNT = R0 / R;
+    static constexpr int NR = N / R;
+    static constexpr int NSL = cq_nsl(LT, P);
+    static constexpr int Ns = 1 << NSL;
+    // element index (inside the band) of output r of butterfly c
+    static __device__ __forceinline__ int out_index(int u, int c, int r) {
+        const int j = u + c * TB;
+        return ((j >> NSL) << (NSL + LR)) + (j & (Ns - 1)) + cq_perm<R>(r) * Ns;
+    }
+    // (LDS addresses: one padded base address per butterfly + compile-time offsets.  With i = i0 + 16 q the padded index is
+    // CQ_AT(i0) + 17 q: every stride that occurs - N/R between the inputs of a butterfly, Ns between its outputs - is a
+    // multiple of 16, or (first pass, Ns = 1) the 16 outputs are one aligned run.)
+    static __device__ __forceinline__ void scatter(const f2* v, f2* a, int base, int u) {
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) {
+            const int j = u + c * TB;
+            f2* ap = a + CQ_AT(base + ((j >> NSL) << (NSL + LR)) + (j & (Ns - 1)));
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                static_assert(Ns == 1 || Ns % 16 == 0, "pass plan");
+                constexpr int unit = Ns == 1 ? 1 : Ns + Ns / 16;
+                ap[cq_perm<R>(r) * unit] = v[c * R + r];
+            }
+        }
+    }
+    // LDS -> registers, twiddles, butterflies (P >= 1)
+    template <int S>
+    static __device__ __forceinline__ void gather_bfly(f2* v, const f2* a, const f2* __restrict__ tw, int base, int u) {
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) {
+            const int j = u + c * TB;
+            f2* x = v + c * R;
+            static_assert(NR % 16 == 0, "pass plan");
+            const f2* ap = a + CQ_AT(base + j);
+#pragma unroll
+            for (int t = 0; t < R; ++t) x[t] = ap[t * (NR + NR / 16)];
+            // W^(k t): t = 1, 2, 4, 8 from the table, the rest as products of two of those (<= 3 roundings)
+            constexpr int stride = 4096 / (Ns * R);
+            const int q1 = (j & (Ns - 1)) * stride;               // < 4096 / R
+            // (table = exp(-2 pi i q/4096): S < 0 multiplies by it, S > 0 by its conjugate)
+            f2 w[R];
+            w[1] = cq_tw(tw, q1);
+            if constexpr (R >= 4) w[2] = cq_tw(tw, 2 * q1);
+            if constexpr (R >= 8) w[4] = cq_tw(tw, 4 * q1);
+            if constexpr (R >= 16) w[8] = cq_tw(tw, 8 * q1);
+#pragma unroll
+            for (int t = 3; t < R; ++t) {
+                const int hb = t >= 8 ? 8 : (t >= 4 ? 4 : 2);      // highest power of two in t
+                if (t != hb) w[t] = cq_mul<false>(w[hb], w[t - hb]);
+            }
+#pragma unroll
+            for (int t = 1; t < R; ++t) x[t] = cq_mul<(S > 0)>(x[t], w[t]);
+            cq_fft<R, S>(x);
+        }
+    }
+};
+
+// The whole transform of the thread's band: `v` enters with the inputs of pass 0 (v[t] = element u + t*TB) and leaves with
+// the outputs of the last pass (CqPass<LT, NP-1>::out_index tells which).  Every thread of the workgroup must call
+// (barriers); `active` guards the LDS traffic of threads without a band.
 template <int LT, int S>
-__device__ __forceinline__ void cq_band_fft(float2* a, const float2* twl, int base, int u, bool active) {
-    if constexpr (LT == 12) { cq_pass<LT, 16, 0, S>(a, twl, base, u, active); cq_pass<LT, 16, 4, S>(a, twl, base, u, active); cq_pass<LT, 16, 8, S>(a, twl, base, u, active); }
-    else if constexpr (LT == 11) { cq_pass<LT, 16, 0, S>(a, twl, base, u, active); cq_pass<LT, 16, 4, S>(a, twl, base, u, active); cq_pass<LT, 8, 8, S>(a, twl, base, u, active); }
-    else if constexpr (LT == 10) { cq_pass<LT, 16, 0, S>(a, twl, base, u, active); cq_pass<LT, 16, 4, S>(a, twl, base, u, active); cq_pass<LT, 4, 8, S>(a, twl, base, u, active); }
-    else if constexpr (LT == 9) { cq_pass<LT, 16, 0, S>(a, twl, base, u, active); cq_pass<LT, 8, 4, S>(a, twl, base, u, active); cq_pass<LT, 4, 7, S>(a, twl, base, u, active); }
-    else if constexpr (LT == 8) { cq_pass<LT, 16, 0, S>(a, twl, base, u, active); cq_pass<LT, 16, 4, S>(a, twl, base, u, active); }
-    else if constexpr (LT == 7) { cq_pass<LT, 16, 0, S>(a, twl, base, u, active); cq_pass<LT, 8, 4, S>(a, twl, base, u, active); }
-    else if constexpr (LT == 6) { cq_pass<LT, 16, 0, S>(a, twl, base, u, active); cq_pass<LT, 4, 4, S>(a, twl, base, u, active); }
-    else if constexpr (LT == 5) { cq_pass<LT, 16, 0, S>(a, twl, base, u, active); cq_pass<LT, 2, 4, S>(a, twl, base, u, active); }
-    else if constexpr (LT == 4) { cq_pass<LT, 16, 0, S>(a, twl, base, u, active); }
-    else if constexpr (LT == 3) { cq_pass<LT, 8, 0, S>(a, twl, base, u, active); }
-    else { cq_pass<LT, 4, 0, S>(a, twl, base, u, active); }
+__device__ __forceinline__ void cq_band_fft_regs(f2* v, f2* a, const f2* __restrict__ tw, int base, int u, bool active) {
+    constexpr int NP = cq_npass(LT);
+    using P0 = CqPass<LT, 0>;
+    cq_fft<P0::R, S>(v);
+    if constexpr (NP >= 2) {
+        using P1 = CqPass<LT, 1>;
+        if (active) P0::scatter(v, a, base, u);
+        __syncthreads();
+        if (active) P1::template gather_bfly<S>(v, a, tw, base, u);
+        if constexpr (NP >= 3) {
+            using P2 = CqPass<LT, 2>;
+            __syncthreads();
+            if (active) P1::scatter(v, a, base, u);
+            __syncthreads();
+            if (active) P2::template gather_bfly<S>(v, a, tw, base, u);
+        }
+    }
 }
 
-// ANALYSIS (MODE 0): a[pos] = spec[(c + m) mod L] * win[m], m = pos for pos < M - M/2, pos - T for pos >= T - M/2, 0 between;
+// ANALYSIS (MODE 0): x[pos] = spec[(c + m) mod L] * win[m], m = pos for pos < M - M/2, pos - T for pos >= T - M/2, 0 between;
 // IFFT_T (unnormalised; win carries 1/T); coefficients out planar.
-// SYNTHESIS (MODE 1): a = coefficients; FFT_T; bs[woff + mi] = A[(mi - M/2) mod T] * win[mi].
+// SYNTHESIS (MODE 1): x = coefficients; FFT_T; bs[woff + mi] = X[(mi - M/2) mod T] * win[mi].
+// Global memory -> registers -> (LDS between passes only) -> registers -> global memory: the inputs of the first pass are
+// loaded in butterfly order (element u + t*T/16 of the band: consecutive threads = consecutive samples) and the outputs of
+// the last pass are stored from registers (runs of Ns >= 16 consecutive samples per instruction).  Round 2 staged the band
+// through LDS before the first and after the last pass and kept the twiddle table in LDS: 256 KB of LDS traffic + 100 KB of
+// twiddle reads + a 16 KB table copy per 4096 points - at B >= 32 the kernel was bound by LDS, not HBM.  Now 128 KB.
 template <int LT, int MODE>
-__device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, float2* a, const float2* twl, const int* bt, int k0,
-                                       int nb, int b, const float* __restrict__ spec, float* __restrict__ bs,
-                                       long bs_stride, const float* __restrict__ win, int abl) {
+__device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, int nb, int b, int B,
+                                       const float* __restrict__ spec, float* __restrict__ bs, long bs_stride,
+                                       const float* __restrict__ win) {
     constexpr int T = 1 << LT;
     constexpr int R0 = T < 16 ? T : 16;
     constexpr int TB = T / R0;
-    constexpr int ITER = (T >= 256) ? 16 : 4096 / 256;        // sweeps of 256 threads over the workgroup's points
+    constexpr int NP = cq_npass(LT);
+    constexpr unsigned OOB = 0x80000000u;                  // beyond every buffer below: loads return 0, stores are dropped
+    using PL = CqPass<LT, NP - 1>;
     const int tid = threadIdx.x;
-    const int npts = nb * T;
-    // bt: the band table of this workgroup in LDS: bt[3*s] = centre bin, bt[3*s+1] = window length, bt[3*s+2] = window offset
-    // ---- load: all 256 threads sweep the points; consecutive threads = consecutive samples of a band.  Addresses first,
-    // then all loads back to back (16 independent loads in flight per thread), then the LDS writes.
-    if (MODE == 0) {
-        const float* sre = spec + (long)b * 2 * bd.KX;
-        float vr[ITER], vi[ITER], vw[ITER];
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int i = tid + it * 256;
-            const int pos = i & (T - 1);
-            const int s = (i >> LT) < nb ? (i >> LT) : nb - 1;
-            const int c = bt[3 * s], M = bt[3 * s + 1], wo = bt[3 * s + 2];
-            const int half = M >> 1;
-            const int m = pos >= T - half ? pos - T : pos;
-            const bool in = (i < npts) && (pos < M - half || pos >= T - half);
-            int n = c + m;
-            n = n < 0 ? n + bd.L : n;
-            n = n >= bd.L ? n - bd.L : n;
-            const bool mir = n > bd.L / 2;
-            const int nn = mir ? bd.L - n : n;
-            const int ns = in ? nn : 0;
-            vr[it] = sre[ns];
-            vi[it] = sre[bd.KX + ns];
-            vw[it] = in ? win[wo + m + half] : 0.f;
-            if (mir) vi[it] = -vi[it];
-        }
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int i = tid + it * 256;
-            if (i < npts) a[CQ_AT(i)] = make_float2(vr[it] * vw[it], vi[it] * vw[it]);
-        }
-    } else {
-        float vr[ITER], vi[ITER];
-        const long imoff = (long)bd.binsoct * T;
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int i = tid + it * 256;
-            const int s = (i >> LT) < nb ? (i >> LT) : nb - 1, pos = i & (T - 1);
-            const int k = k0 + s;       // bands of a workgroup belong to one octave: consecutive bins
-            const float* in = bd.coef[bd.oct[k0]] + ((long)b * 2 * bd.binsoct + (bd.binoct[k0] + s)) * T;
-            vr[it] = in[pos];
-            vi[it] = in[imoff + pos];
-            (void)k;
-        }
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int i = tid + it * 256;
-            if (i < npts) a[CQ_AT(i)] = make_float2(vr[it], vi[it]);
-        }
-    }
-    __syncthreads();
     const int s = tid / TB, u = tid % TB;
-    if (!(abl & 1)) cq_band_fft<LT, (MODE == 0 ? +1 : -1)>(a, twl, s << LT, u, s < nb);
-    // ---- store
+    const bool active = s < nb;
+    const int k = k0 + (active ? s : 0);
+    const int M = bd.M[k], wo = bd.woff[k], half = M >> 1;
+    const f2* tw = reinterpret_cast<const f2*>(bd.tw4096);
+    // All global traffic goes through buffer descriptors: 32-bit per-thread offsets, the compile-time part of an address in
+    // the instruction's scalar offset, the range check as the "outside the window" zero - the kernel is bound by the
+    // vector ALU (round 3 PMC: 1100 vector instructions per thread and 16 points, a third of them address arithmetic).
+    // coefficients of the workgroup's octave, clip b: [2][binsoct][T]; bands of a workgroup are consecutive bins
+    const int oc = bd.oct[k0];
+    const unsigned plane = (unsigned)bd.binsoct * T * 4;                                   // bytes of the real plane
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(bd.coef[oc] + (long)b * 2 * bd.binsoct * T, 0, 2 * plane, 0x00020000);
+    const unsigned cfo = active ? (unsigned)((bd.binoct[k0] + s) * T) * 4 : OOB;           // this thread's band
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)win, 0, (unsigned)bd.sum_M * 4, 0x00020000);
+    f2 v[R0];
     if (MODE == 0) {
-        float* out0 = bd.coef[bd.oct[k0]] + ((long)b * 2 * bd.binsoct + bd.binoct[k0]) * T;
-        const long imoff = (long)bd.binsoct * T;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(spec + (long)b * 2 * bd.KX), 0, 2 * (unsigned)bd.KX * 4, 0x00020000);
+        const int c = bd.c[k];
+        const unsigned im = (unsigned)bd.KX * 4;
+        float vr[R0], vi[R0], vw[R0];
+        // the band's window covers spectrum bins c - half .. c + M - half - 1; almost every band lies inside 0 .. L/2
+        if (c - half >= 0 && c + M - half - 1 <= bd.L / 2) {
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int i = tid + it * 256;              // bands of the workgroup are consecutive bins: out0 + i
-            if (i < npts) {
-                const float2 v = a[CQ_AT(i)];
-                out0[i] = v.x;
-                out0[imoff + i] = v.y;
+            for (int t = 0; t < R0; ++t) {
+                const int pos = u + t * TB;
+                const bool hi = pos >= T - half;
+                const bool in = active && (pos < M - half || hi);
+                const int m = hi ? pos - T : pos;
+                const unsigned so = in ? (unsigned)(c + m) * 4 : OOB;
+                const unsigned wv = in ? (unsigned)(wo + half + m) * 4 : OOB;
+                vr[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, 0, 0));
+                vi[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, im, 0));
+                vw[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wv, 0, 0));
+            }
+        } else {                                          // bands that wrap around bin 0 or reach past L/2 (mirror: conjugate)
+#pragma unroll
+            for (int t = 0; t < R0; ++t) {
+                const int pos = u + t * TB;
+                const int m = pos >= T - half ? pos - T : pos;
+                const bool in = active && (pos < M - half || pos >= T - half);
+                int n = c + m;
+                n = n < 0 ? n + bd.L : n;
+                n = n >= bd.L ? n - bd.L : n;
+                const bool mir = n > bd.L / 2;
+                const int nn = mir ? bd.L - n : n;
+                const unsigned so = in ? (unsigned)nn * 4 : OOB;
+                const unsigned wv = in ? (unsigned)(wo + half + m) * 4 : OOB;
+                vr[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, 0, 0));
+                vi[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, im, 0));
+                vw[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wv, 0, 0));
+                if (mir) vi[t] = -vi[t];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < R0; ++t) v[t] = f2{vr[t], vi[t]} * vw[t];
+    } else {
+        float vr[R0], vi[R0];
+#pragma unroll
+        for (int t = 0; t < R0; ++t) {
+            vr[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, cfo + u * 4, t * TB * 4, 0));
+            vi[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, cfo + u * 4, plane + t * TB * 4, 0));
+        }
+#pragma unroll
+        for (int t = 0; t < R0; ++t) v[t] = f2{vr[t], vi[t]};
+    }
+    cq_band_fft_regs<LT, (MODE == 0 ? +1 : -1)>(v, a, tw, s << LT, u, active);
+    if (MODE == 0) {
+#pragma unroll
+        for (int c = 0; c < PL::CNT; ++c) {
+            const unsigned o0 = cfo + (unsigned)PL::out_index(u, c, 0) * 4;                // (cq_perm(0) = 0)
+#pragma unroll
+            for (int r = 0; r < PL::R; ++r) {
+                const int d = cq_perm<PL::R>(r) * PL::Ns * 4;
+                // (floats first: hipcc 7.2 miscompiles __builtin_bit_cast of an ext_vector ELEMENT - it reads element 0)
+                const float yr = v[c * PL::R + r].x, yi = v[c * PL::R + r].y;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(yr), rc, o0, d, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(yi), rc, o0, plane + d, 0);
             }
         }
     } else {
-        // window samples of the workgroup's bands are contiguous in the band-spectrum buffer
-        const int w0 = bt[2];
-        const int w1 = bt[3 * (nb - 1) + 2] + bt[3 * (nb - 1) + 1];
-        float2* o = reinterpret_cast<float2*>(bs) + (long)b * bs_stride;
-        int s2 = 0;
-        for (int wi = w0 + tid; wi < w1; wi += 256) {
-            while (s2 + 1 < nb && wi >= bt[3 * (s2 + 1) + 2]) ++s2;
-            const int mi = wi - bt[3 * s2 + 2];
-            const int m = mi - (bt[3 * s2 + 1] >> 1);
-            const float2 v = a[CQ_AT((s2 << LT) + (m & (T - 1)))];
-            const float w = win[wi];
-            o[wi] = make_float2(v.x * w, v.y * w);
-        }
+        // band spectra: [B][sum_M] complex; one descriptor over the whole tensor would pass 4 GB at large B: per clip
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(bs + (long)b * bs_stride * 2, 0, (unsigned)bd.sum_M * 8, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < PL::CNT; ++c)
+#pragma unroll
+            for (int r = 0; r < PL::R; ++r) {
+                const int mi = (PL::out_index(u, c, r) + half) & (T - 1);
+                const bool ok = active && mi < M;
+                const float w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, ok ? (unsigned)(wo + mi) * 4 : OOB, 0, 0));
+                const f2 o = v[c * PL::R + r] * w;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, o), ro, ok ? (unsigned)(wo + mi) * 8 : OOB, 0, 0);
+            }
     }
 }
 
@@ -240,63 +320,63 @@ template <int MODE>
 __global__ __launch_bounds__(256) void band_fft_kernel(babe_cqt_bands bd, const float* __restrict__ spec,
                                                        float* __restrict__ bs, long bs_stride,
                                                        const float* __restrict__ win) {
-    __shared__ float2 a[CQ_LDS];
-    __shared__ float2 twl[2048];
-    __shared__ int bt[3 * 64];
+    __shared__ f2 a[CQ_LDS];
     const int wg = blockIdx.x, b = blockIdx.y;
     const int k0 = bd.wg_first[wg], nb = bd.wg_count[wg], lt = bd.log2T[k0];
     if (nb > 64 || (nb << lt) > 4096) __builtin_trap();      // a table that contradicts its own summary fields: fail loudly
-    // twiddle table -> LDS: loads issued first, written after (they are not needed before the second pass; the barrier at
-    // the end of the load phase covers them)
-    const float2* tw = reinterpret_cast<const float2*>(bd.tw4096);
-    float2 twr[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) twr[i] = tw[threadIdx.x + i * 256];
-    if (threadIdx.x < nb) {
-        bt[3 * threadIdx.x] = bd.c[k0 + threadIdx.x];
-        bt[3 * threadIdx.x + 1] = bd.M[k0 + threadIdx.x];
-        bt[3 * threadIdx.x + 2] = bd.woff[k0 + threadIdx.x];
-    }
-    if (MODE == 0) __syncthreads();            // (synthesis needs the table only after its load-phase barrier)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) twl[threadIdx.x + i * 256] = twr[i];
-#ifdef BABE_CQT_ABL
-    const int abl = bd.abl;
-#else
-    constexpr int abl = 0;
-#endif
     switch (lt) {
-#define CQ_CASE(L_) case L_: cq_run<L_, MODE>(bd, a, twl, bt, k0, nb, b, spec, bs, bs_stride, win, abl); break;
+#define CQ_CASE(L_) case L_: cq_run<L_, MODE>(bd, a, k0, nb, b, gridDim.y, spec, bs, bs_stride, win); break;
+#ifdef CQ_ONLY                    // (instruction counting: one band length per build)
+        CQ_CASE(CQ_ONLY)
+#else
         CQ_CASE(12) CQ_CASE(11) CQ_CASE(10) CQ_CASE(9) CQ_CASE(8) CQ_CASE(7) CQ_CASE(6) CQ_CASE(5) CQ_CASE(4) CQ_CASE(3) CQ_CASE(2)
+#endif
 #undef CQ_CASE
         default: __builtin_trap();
     }
 }
 
+// overlap-add in frequency as a CSR gather (deterministic: fixed summation order, no atomics).  A thread owns bin n of GB
+// consecutive clips: the row pointers / source indices (the same for every clip) are loaded once per GB clips.
+constexpr int GB = 4;
 __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ bs, long bs_stride,
                                                      const int* __restrict__ rowptr, const int* __restrict__ src,
                                                      float* __restrict__ spec, int KX, int L, float scale,
-                                                     const float* __restrict__ mul) {
-    const int b = blockIdx.y;
+                                                     const float* __restrict__ mul, int B) {
+    const int b0 = blockIdx.y * GB;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= KX) return;
-    float re = 0.f, im = 0.f;
+    float re[GB], im[GB];
+#pragma unroll
+    for (int i = 0; i < GB; ++i) re[i] = im[i] = 0.f;
     if (n <= L / 2) {
-        const float2* p = reinterpret_cast<const float2*>(bs) + (long)b * bs_stride;
+        const float2* p = reinterpret_cast<const float2*>(bs) + (long)b0 * bs_stride;
         const int e0 = rowptr[n], e1 = rowptr[n + 1];
         for (int e = e0; e < e1; ++e) {
             const int s = src[e];
-            const float2 v = p[s & 0x7fffffff];
-            re += v.x;
-            im += (s < 0) ? -v.y : v.y;
+            const int si = s & 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < GB; ++i)
+                if (b0 + i < B) {
+                    const float2 v = p[(long)i * bs_stride + si];
+                    re[i] += v.x;
+                    im[i] += (s < 0) ? -v.y : v.y;
+                }
         }
         float sc = scale;
         if (mul) sc *= mul[n];
-        re *= sc;
-        im *= sc;
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            re[i] *= sc;
+            im[i] *= sc;
+        }
     }
-    spec[(long)b * 2 * KX + n] = re;
-    spec[(long)b * 2 * KX + KX + n] = im;
+#pragma unroll
+    for (int i = 0; i < GB; ++i)
+        if (b0 + i < B) {
+            spec[(long)(b0 + i) * 2 * KX + n] = re[i];
+            spec[(long)(b0 + i) * 2 * KX + KX + n] = im[i];
+        }
 }
 
 __global__ __launch_bounds__(256) void spec_scale_kernel(const float* __restrict__ s1, const float* __restrict__ s2,
@@ -402,7 +482,7 @@ static int check_bands(const babe_cqt_bands* bd) {
     BABE_CHECK_ARG(bd && bd->nbands > 0 && bd->c && bd->M && bd->woff && bd->log2T && bd->oct && bd->binoct &&
                        bd->tw4096 && bd->nocts <= 8 && bd->wg_first && bd->wg_count && bd->nwg > 0,
                    "cqt: bad band table");
-    // what the band-FFT kernel relies on: <= 64 bands per workgroup (its LDS band table), T in 4..4096 (its dispatch)
+    // what the band-FFT kernel relies on: <= 64 bands per workgroup (thread = band slot x butterfly), T in 4..4096 (its dispatch)
     BABE_CHECK_ARG(bd->max_wg_count >= 1 && bd->max_wg_count <= 64, "cqt: wg_count must be in 1..64 (got %d)", bd->max_wg_count);
     BABE_CHECK_ARG(bd->min_log2T >= 2 && bd->max_log2T <= 12 && bd->min_log2T <= bd->max_log2T,
                    "cqt: band lengths must be 2^2..2^12 (got 2^%d..2^%d)", bd->min_log2T, bd->max_log2T);
@@ -436,8 +516,8 @@ extern "C" int babe_cqt_gather(const float* bs, long bs_stride, const int* rowpt
                                int L, float scale, const float* mul, int B, void* stream) {
     BABE_CHECK_ARG(bs && rowptr && src && spec && KX > L / 2 && B > 0, "cqt_gather: bad arguments");
     BabeProfScope prof(BABE_SLOT_CQT_GATHER, (double)B * 8.0 * (bs_stride + KX), 0, 0, stream);
-    hipLaunchKernelGGL(gather_kernel, dim3(cdiv(KX, 256), B), dim3(256), 0, (hipStream_t)stream, bs, bs_stride, rowptr,
-                       src, spec, KX, L, scale, mul);
+    hipLaunchKernelGGL(gather_kernel, dim3(cdiv(KX, 256), cdiv(B, GB)), dim3(256), 0, (hipStream_t)stream, bs, bs_stride,
+                       rowptr, src, spec, KX, L, scale, mul, B);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

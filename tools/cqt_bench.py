@@ -9,7 +9,7 @@ from babe_amd.cqt import CQT_nsgt
 L, fs = 368368, 44100
 cq = CQT_nsgt(7, 64, "oct", ("kaiser", 1), fs, L, device="cuda")
 ncoef = sum(64 * T for T in cq.T_oct)
-for B in (1, 2, 8, 32, 64):
+for B in [int(v) for v in os.environ.get("BS", "1,2,8,32,64").split(",")]:
     x = torch.randn(B, L, device="cuda")
     spec = cq.fft.rfft(x)
     coefs = cq.alloc_coefs(B)
