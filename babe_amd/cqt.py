@@ -122,7 +122,8 @@ class _BandsStruct(C.Structure):
                 ("c", C.c_void_p), ("M", C.c_void_p), ("woff", C.c_void_p), ("log2T", C.c_void_p),
                 ("oct", C.c_void_p), ("binoct", C.c_void_p), ("tw4096", C.c_void_p),
                 ("nocts", C.c_int), ("binsoct", C.c_int), ("coef", C.c_void_p * 8),
-                ("wg_first", C.c_void_p), ("wg_count", C.c_void_p), ("nwg", C.c_int), ("abl", C.c_int),
+                ("wg_first", C.c_void_p), ("wg_count", C.c_void_p), ("nwg", C.c_int),
+                ("wg_rec", C.c_void_p), ("band_rec", C.c_void_p), ("abl", C.c_int),
                 ("max_wg_count", C.c_int), ("min_log2T", C.c_int), ("max_log2T", C.c_int),
                 ("sum_T", C.c_long), ("sum_M", C.c_long), ("sum_TlogT", C.c_double)]
 
@@ -133,7 +134,7 @@ def _register_sigs():
     L.babe_fft_twiddle_transpose.argtypes = [P, P, P, I, I, I, I, P]
     L.babe_cqt_band_analysis.argtypes = [C.POINTER(_BandsStruct), P, P, I, P]
     L.babe_cqt_band_synthesis.argtypes = [C.POINTER(_BandsStruct), P, P, Lg, I, P]
-    L.babe_cqt_gather.argtypes = [P, Lg, P, P, P, I, I, F, P, I, P]
+    L.babe_cqt_gather.argtypes = [P, Lg, P, P, P, P, I, I, F, P, I, P]
     L.babe_spec_scale.argtypes = [P, P, P, P, I, I, F, F, I, P]
     for n in ("babe_fft_twiddle_transpose", "babe_cqt_band_analysis", "babe_cqt_band_synthesis", "babe_cqt_gather",
               "babe_spec_scale"):
@@ -247,6 +248,11 @@ class CQT_nsgt:
                 wgf.append(j * binsoct + s0)
                 wgc.append(min(bpw, binsoct - s0))
         self._tabs["wg_first"], self._tabs["wg_count"] = ti(wgf), ti(wgc)
+        # packed copies for the kernel: one 16-byte record per workgroup / per band
+        l2b = np.log2(d["T"]).astype(np.int64)
+        self._tabs["wg_rec"] = ti(np.stack([np.asarray(wgf), np.asarray(wgc), l2b[wgf],
+                                            (np.asarray(wgf) // binsoct) | ((np.asarray(wgf) % binsoct) << 8)], 1).reshape(-1))
+        self._tabs["band_rec"] = ti(np.stack([d["c"], d["M"], d["woff"], np.zeros_like(d["c"])], 1).reshape(-1))
         self.nwg = len(wgf)
         self._wg_max = int(max(wgc))
         l2 = np.log2(d["T"]).astype(np.int64)
@@ -261,6 +267,17 @@ class CQT_nsgt:
         self.rowptr = ti(d["rowptr"])
         self.src = torch.tensor(np.asarray(d["src"], dtype=np.int64).astype(np.int32), dtype=torch.int32, device=dev)
         self.nwin = d["nwin"]
+        # the CSR as fixed 16-byte records {src0, src1, src2, count} when no bin has more than three sources
+        rp, sr = np.asarray(d["rowptr"]), np.asarray(d["src"], dtype=np.int64)
+        cnt = np.diff(rp)
+        self.rec = None
+        if cnt.max() <= 3:
+            rec = np.zeros((L // 2 + 1, 4), dtype=np.int64)
+            for e in range(3):
+                has = cnt > e
+                rec[has, e] = sr[rp[:-1][has] + e]
+            rec[:, 3] = cnt
+            self.rec = torch.tensor(rec.astype(np.int32).reshape(-1), dtype=torch.int32, device=dev)
         self.hpf = tf(d["hpf"])                           # real response on bins 0..L/2
         cw = np.full(L // 2 + 1, 2.0 / L)
         cw[0] = cw[-1] = 1.0 / L
@@ -272,7 +289,7 @@ class CQT_nsgt:
         s = _BandsStruct()
         d = self.design
         s.nbands, s.L, s.KX = d["nb"], self.Ls, self.fft.KX
-        for k in ("c", "M", "woff", "log2T", "oct", "binoct", "wg_first", "wg_count"):
+        for k in ("c", "M", "woff", "log2T", "oct", "binoct", "wg_first", "wg_count", "wg_rec", "band_rec"):
             setattr(s, k, ptr(self._tabs[k]))
         s.nwg = self.nwg
         s.abl = 0                                         # (ablation builds only: tools/abl_build.sh -DBABE_CQT_ABL)
@@ -303,8 +320,8 @@ class CQT_nsgt:
         check(lib().babe_cqt_band_synthesis(C.byref(s), ptr(bs), ptr(win), self.nwin, B, stream()), "cqt_band_synthesis")
         if spec is None:
             spec = torch.empty(B, 2, self.fft.KX, device=self.device)
-        check(lib().babe_cqt_gather(ptr(bs), self.nwin, ptr(self.rowptr), ptr(self.src), ptr(spec), self.fft.KX,
-                                    self.Ls, scale, ptr(mul), B, stream()), "cqt_gather")
+        check(lib().babe_cqt_gather(ptr(bs), self.nwin, ptr(self.rowptr), ptr(self.src), ptr(self.rec), ptr(spec),
+                                    self.fft.KX, self.Ls, scale, ptr(mul), B, stream()), "cqt_gather")
         return spec
 
     def spec_scale(self, s1, mul, sc1=1.0, s2=None, sc2=0.0, out=None):

@@ -210,7 +210,7 @@ __device__ __forceinline__ void cq_band_fft_regs(f2* v, f2* a, const f2* __restr
 // through LDS before the first and after the last pass and kept the twiddle table in LDS: 256 KB of LDS traffic + 100 KB of
 // twiddle reads + a 16 KB table copy per 4096 points - at B >= 32 the kernel was bound by LDS, not HBM.  Now 128 KB.
 template <int LT, int MODE>
-__device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, int nb, int b, int B,
+__device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, int nb, int oc, int bin0, int b,
                                        const float* __restrict__ spec, float* __restrict__ bs, long bs_stride,
                                        const float* __restrict__ win) {
     constexpr int T = 1 << LT;
@@ -223,21 +223,22 @@ __device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, 
     const int s = tid / TB, u = tid % TB;
     const bool active = s < nb;
     const int k = k0 + (active ? s : 0);
-    const int M = bd.M[k], wo = bd.woff[k], half = M >> 1;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 br = reinterpret_cast<const i32x4*>(bd.band_rec)[k];          // {c, M, woff, 0}
+    const int M = br[1], wo = br[2], half = M >> 1;
     const f2* tw = reinterpret_cast<const f2*>(bd.tw4096);
     // All global traffic goes through buffer descriptors: 32-bit per-thread offsets, the compile-time part of an address in
     // the instruction's scalar offset, the range check as the "outside the window" zero - the kernel is bound by the
     // vector ALU (round 3 PMC: 1100 vector instructions per thread and 16 points, a third of them address arithmetic).
     // coefficients of the workgroup's octave, clip b: [2][binsoct][T]; bands of a workgroup are consecutive bins
-    const int oc = bd.oct[k0];
     const unsigned plane = (unsigned)bd.binsoct * T * 4;                                   // bytes of the real plane
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(bd.coef[oc] + (long)b * 2 * bd.binsoct * T, 0, 2 * plane, 0x00020000);
-    const unsigned cfo = active ? (unsigned)((bd.binoct[k0] + s) * T) * 4 : OOB;           // this thread's band
+    const unsigned cfo = active ? (unsigned)((bin0 + s) * T) * 4 : OOB;                    // this thread's band
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)win, 0, (unsigned)bd.sum_M * 4, 0x00020000);
     f2 v[R0];
     if (MODE == 0) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(spec + (long)b * 2 * bd.KX), 0, 2 * (unsigned)bd.KX * 4, 0x00020000);
-        const int c = bd.c[k];
+        const int c = br[0];
         const unsigned im = (unsigned)bd.KX * 4;
         float vr[R0], vi[R0], vw[R0];
         // the band's window covers spectrum bins c - half .. c + M - half - 1; almost every band lies inside 0 .. L/2
@@ -322,10 +323,12 @@ __global__ __launch_bounds__(256) void band_fft_kernel(babe_cqt_bands bd, const 
                                                        const float* __restrict__ win) {
     __shared__ f2 a[CQ_LDS];
     const int wg = blockIdx.x, b = blockIdx.y;
-    const int k0 = bd.wg_first[wg], nb = bd.wg_count[wg], lt = bd.log2T[k0];
-    if (nb > 64 || (nb << lt) > 4096) __builtin_trap();      // a table that contradicts its own summary fields: fail loudly
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 wr = reinterpret_cast<const i32x4*>(bd.wg_rec)[wg];           // {first band, bands, log2 T, oct | binoct << 8}
+    const int k0 = wr[0], nb = wr[1], lt = wr[2], oc = wr[3] & 255, bin0 = wr[3] >> 8;
+    if (nb > 64 || (nb << lt) > 4096 || oc >= 8) __builtin_trap();      // a table that contradicts its own summary fields: fail loudly
     switch (lt) {
-#define CQ_CASE(L_) case L_: cq_run<L_, MODE>(bd, a, k0, nb, b, gridDim.y, spec, bs, bs_stride, win); break;
+#define CQ_CASE(L_) case L_: cq_run<L_, MODE>(bd, a, k0, nb, oc, bin0, b, spec, bs, bs_stride, win); break;
 #ifdef CQ_ONLY                    // (instruction counting: one band length per build)
         CQ_CASE(CQ_ONLY)
 #else
@@ -336,13 +339,17 @@ __global__ __launch_bounds__(256) void band_fft_kernel(babe_cqt_bands bd, const 
     }
 }
 
-// overlap-add in frequency as a CSR gather (deterministic: fixed summation order, no atomics).  A thread owns bin n of GB
-// consecutive clips: the row pointers / source indices (the same for every clip) are loaded once per GB clips.
-constexpr int GB = 4;
-__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ bs, long bs_stride,
-                                                     const int* __restrict__ rowptr, const int* __restrict__ src,
-                                                     float* __restrict__ spec, int KX, int L, float scale,
-                                                     const float* __restrict__ mul, int B) {
+// overlap-add in frequency as a gather (deterministic: fixed summation order, no atomics).  A thread owns bin n of GB
+// consecutive clips; the sources of a bin (the same for every clip) come as ONE 16-byte record {s0, s1, s2, count} built from
+// the CSR on the host when no bin has more than three (NSGT windows overlap pairwise; a third source appears where rounded
+// window lengths or the mirrored bands reach one bin further) - round 2 walked rowptr -> src -> data, three dependent
+// loads deep, and the kernel took as long as the band FFTs.  Sources beyond the count get an out-of-range offset and load 0.
+constexpr int GB = 8;
+__global__ __launch_bounds__(256) void gather_rec_kernel(const float* __restrict__ bs, long bs_stride, unsigned bs_bytes,
+                                                         const int* __restrict__ rec, float* __restrict__ spec, int KX,
+                                                         int L, float scale, const float* __restrict__ mul, int B) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int b0 = blockIdx.y * GB;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= KX) return;
@@ -350,23 +357,33 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ b
 #pragma unroll
     for (int i = 0; i < GB; ++i) re[i] = im[i] = 0.f;
     if (n <= L / 2) {
-        const float2* p = reinterpret_cast<const float2*>(bs) + (long)b0 * bs_stride;
-        const int e0 = rowptr[n], e1 = rowptr[n + 1];
-        for (int e = e0; e < e1; ++e) {
-            const int s = src[e];
-            const int si = s & 0x7fffffff;
+        const i32x4 r = reinterpret_cast<const i32x4*>(rec)[n];
+        unsigned off[3];
+        float sg[3];
 #pragma unroll
-            for (int i = 0; i < GB; ++i)
-                if (b0 + i < B) {
-                    const float2 v = p[(long)i * bs_stride + si];
-                    re[i] += v.x;
-                    im[i] += (s < 0) ? -v.y : v.y;
-                }
+        for (int e = 0; e < 3; ++e) {
+            off[e] = e < r[3] ? (unsigned)(r[e] & 0x7fffffff) * 8u : 0x80000000u;
+            sg[e] = r[e] < 0 ? -1.f : 1.f;
         }
         float sc = scale;
         if (mul) sc *= mul[n];
+        f32x2 v[GB][3];
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
+            // (clips past the batch: a zero-length descriptor, every load returns 0)
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bs + (long)(b0 + i < B ? b0 + i : 0) * bs_stride * 2), 0,
+                                                                                b0 + i < B ? bs_bytes : 0u, 0x00020000);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) v[i][e] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rb, off[e], 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const float vx = v[i][e].x, vy = v[i][e].y;
+                re[i] += vx;
+                im[i] += sg[e] * vy;
+            }
             re[i] *= sc;
             im[i] *= sc;
         }
@@ -377,6 +394,33 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ b
             spec[(long)(b0 + i) * 2 * KX + n] = re[i];
             spec[(long)(b0 + i) * 2 * KX + KX + n] = im[i];
         }
+}
+
+// general form (any number of sources per bin): walks the CSR
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ bs, long bs_stride,
+                                                     const int* __restrict__ rowptr, const int* __restrict__ src,
+                                                     float* __restrict__ spec, int KX, int L, float scale,
+                                                     const float* __restrict__ mul) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= KX) return;
+    float re = 0.f, im = 0.f;
+    if (n <= L / 2) {
+        const float2* p = reinterpret_cast<const float2*>(bs) + (long)b * bs_stride;
+        const int e0 = rowptr[n], e1 = rowptr[n + 1];
+        for (int e = e0; e < e1; ++e) {
+            const int s = src[e];
+            const float2 v = p[s & 0x7fffffff];
+            re += v.x;
+            im += (s < 0) ? -v.y : v.y;
+        }
+        float sc = scale;
+        if (mul) sc *= mul[n];
+        re *= sc;
+        im *= sc;
+    }
+    spec[(long)b * 2 * KX + n] = re;
+    spec[(long)b * 2 * KX + KX + n] = im;
 }
 
 __global__ __launch_bounds__(256) void spec_scale_kernel(const float* __restrict__ s1, const float* __restrict__ s2,
@@ -480,7 +524,7 @@ extern "C" int babe_fft_twiddle_transpose(const float* in, float* out, const flo
 
 static int check_bands(const babe_cqt_bands* bd) {
     BABE_CHECK_ARG(bd && bd->nbands > 0 && bd->c && bd->M && bd->woff && bd->log2T && bd->oct && bd->binoct &&
-                       bd->tw4096 && bd->nocts <= 8 && bd->wg_first && bd->wg_count && bd->nwg > 0,
+                       bd->tw4096 && bd->nocts <= 8 && bd->wg_first && bd->wg_count && bd->nwg > 0 && bd->wg_rec && bd->band_rec,
                    "cqt: bad band table");
     // what the band-FFT kernel relies on: <= 64 bands per workgroup (thread = band slot x butterfly), T in 4..4096 (its dispatch)
     BABE_CHECK_ARG(bd->max_wg_count >= 1 && bd->max_wg_count <= 64, "cqt: wg_count must be in 1..64 (got %d)", bd->max_wg_count);
@@ -512,12 +556,16 @@ extern "C" int babe_cqt_band_synthesis(const babe_cqt_bands* bd, float* bs, cons
     return BABE_OK;
 }
 
-extern "C" int babe_cqt_gather(const float* bs, long bs_stride, const int* rowptr, const int* src, float* spec, int KX,
-                               int L, float scale, const float* mul, int B, void* stream) {
+extern "C" int babe_cqt_gather(const float* bs, long bs_stride, const int* rowptr, const int* src, const int* rec,
+                               float* spec, int KX, int L, float scale, const float* mul, int B, void* stream) {
     BABE_CHECK_ARG(bs && rowptr && src && spec && KX > L / 2 && B > 0, "cqt_gather: bad arguments");
     BabeProfScope prof(BABE_SLOT_CQT_GATHER, (double)B * 8.0 * (bs_stride + KX), 0, 0, stream);
-    hipLaunchKernelGGL(gather_kernel, dim3(cdiv(KX, 256), cdiv(B, GB)), dim3(256), 0, (hipStream_t)stream, bs, bs_stride,
-                       rowptr, src, spec, KX, L, scale, mul, B);
+    if (rec && bs_stride * 8 < 0x80000000L)
+        hipLaunchKernelGGL(gather_rec_kernel, dim3(cdiv(KX, 256), cdiv(B, GB)), dim3(256), 0, (hipStream_t)stream, bs,
+                           bs_stride, (unsigned)(bs_stride * 8), rec, spec, KX, L, scale, mul, B);
+    else
+        hipLaunchKernelGGL(gather_kernel, dim3(cdiv(KX, 256), B), dim3(256), 0, (hipStream_t)stream, bs, bs_stride, rowptr,
+                           src, spec, KX, L, scale, mul);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

@@ -171,6 +171,10 @@ typedef struct {
     /* workgroup table: workgroup w transforms bands wg_first[w] .. wg_first[w]+wg_count[w]-1, all of one octave
      * (same T), wg_count[w] * T <= 4096 points */
     const int* wg_first; const int* wg_count; int nwg;
+    /* the same tables packed for the kernel (one 16-byte load each instead of chains of dependent 4-byte loads - a
+     * workgroup lives ~6 us and spent a third of that fetching its own description):
+     * wg_rec[w] = {wg_first, wg_count, log2T, oct | binoct << 8},  band_rec[k] = {c, M, woff, 0}   (int4 each) */
+    const int* wg_rec; const int* band_rec;
     int abl;             /* timing-only ablation bits (1: skip the FFT passes); read only by -DBABE_CQT_ABL builds */
     /* host-side summary of the DEVICE tables above, validated by the entry points (the kernel keeps wg_count bands of
      * 3 ints in LDS and dispatches on log2T): max of wg_count (<= 64), min / max of log2T (2..12) */
@@ -186,9 +190,11 @@ int babe_cqt_band_analysis(const babe_cqt_bands* bands, const float* spec, const
 int babe_cqt_band_synthesis(const babe_cqt_bands* bands, float* bs, const float* win, long bs_stride, int B,
                             void* stream);
 /* spec[b][:, n] = scale * sum over CSR entries of n of bs (conjugated when the entry's sign bit is set);
- * optionally multiplied by mul[n] (real, e.g. the DC/Nyquist high-pass) ; n > L/2 -> 0. */
-int babe_cqt_gather(const float* bs, long bs_stride, const int* rowptr, const int* src, float* spec, int KX,
-                    int L, float scale, const float* mul, int B, void* stream);
+ * optionally multiplied by mul[n] (real, e.g. the DC/Nyquist high-pass) ; n > L/2 -> 0.
+ * rec (optional, [L/2+1] int4): the same CSR as fixed records {src0, src1, src2, count}, count <= 3 for every bin; when
+ * given, the record kernel runs (same sums in the same order), otherwise the CSR walk. */
+int babe_cqt_gather(const float* bs, long bs_stride, const int* rowptr, const int* src, const int* rec, float* spec,
+                    int KX, int L, float scale, const float* mul, int B, void* stream);
 /* spec_out = spec_in * mul[n] * scale for n <= L/2, 0 above (apply_hpf_DC in the frequency domain);
  * optional second term: spec_out += spec2 * mul[n] * scale2. */
 int babe_spec_scale(const float* spec_in, const float* spec2, float* spec_out, const float* mul, int KX, int L,

@@ -28,22 +28,23 @@ for B in [int(v) for v in os.environ.get("BS", "1,2,8,32,64").split(",")]:
     t_sy = timeit(lambda: cq.synthesis_spec(coefs, cq.win_bwd, 2.0 / L))
     t_fft = timeit(lambda: cq.fft.rfft(x))
     by = B * ((L // 2 + 1) * 8 + ncoef * 8)
-    # GPU-side durations (HIP events around each launch, the library's measurement hook): the loop above is bound by the
-    # Python call rate (~20 us) at small B
-    _lib.prof_read()
-    _lib.prof_enable(True)
-    for _ in range(20):
-        cq.analysis(spec, cq.win_fwd, coefs)
-        cq.synthesis_spec(coefs, cq.win_bwd, 2.0 / L)
-        cq.fft.rfft(x)
-    torch.cuda.synchronize()
-    _lib.prof_enable(False)
-    pr = _lib.prof_read()
-    ev = {k: (pr[k]["ms"] * 1e3 / max(pr[k]["launches"], 1), pr[k]["bytes"] / max(pr[k]["ms"], 1e-9) / 1e6) for k in
-          ("cqt_band_analysis", "cqt_band_synthesis", "cqt_gather", "dft_stage")}
-    print(f"B={B:3d} [HIP events] band_analysis {ev['cqt_band_analysis'][0]:7.1f} us {ev['cqt_band_analysis'][1]:7.0f} GB/s "
-          f"({ev['cqt_band_analysis'][1] / 80:5.1f}% of 8 TB/s) | band_synthesis {ev['cqt_band_synthesis'][0]:7.1f} us "
-          f"{ev['cqt_band_synthesis'][1]:7.0f} GB/s ({ev['cqt_band_synthesis'][1] / 80:5.1f}%) | gather "
-          f"{ev['cqt_gather'][0]:6.1f} us | DFT stages (2 per rfft_L) {ev['dft_stage'][0]:7.1f} us each")
-    print(f"B={B:3d} analysis {t_an*1e3:8.1f} us {by/t_an/1e6:8.1f} GB/s ({by/t_an/1e6/8000*100:5.1f}% of 8 TB/s) | "
-          f"synthesis(+gather) {t_sy*1e3:8.1f} us {by/t_sy/1e6:8.1f} GB/s | rfft_L {t_fft*1e3:8.1f} us")
+    # GPU-side durations (HIP events around each launch, the library's measurement hook), one operation at a time - the
+    # slots are shared (twiddle_transpose / spec_scale also report into "cqt_gather").  The Python loop above is bound by
+    # the call rate (~20 us per call) at small B.
+    def gpu_us(fn, slots, n=20):
+        _lib.prof_read()
+        _lib.prof_enable(True)
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        pr = _lib.prof_read()
+        return [pr[k]["ms"] * 1e3 / max(pr[k]["launches"], 1) for k in slots]
+    g_an, = gpu_us(lambda: cq.analysis(spec, cq.win_fwd, coefs), ["cqt_band_analysis"])
+    g_sy, g_ga = gpu_us(lambda: cq.synthesis_spec(coefs, cq.win_bwd, 2.0 / L), ["cqt_band_synthesis", "cqt_gather"])
+    g_dft, g_tt = gpu_us(lambda: cq.fft.rfft(x), ["dft_stage", "cqt_gather"])
+    tb = lambda us: by / us / 1e6          # algorithmic bytes (5.63 MB per clip) / GPU time -> TB/s
+    print(f"B={B:3d} [GPU time, HIP events] band_analysis {g_an:7.1f} us = {tb(g_an):5.2f} TB/s ({tb(g_an) / 8 * 100:4.1f}% of 8 TB/s) | "
+          f"band_synthesis {g_sy:7.1f} us + gather {g_ga:6.1f} us = {tb(g_sy + g_ga):5.2f} TB/s ({tb(g_sy + g_ga) / 8 * 100:4.1f}%) "
+          f"[band_synthesis alone {tb(g_sy):5.2f} TB/s] | rfft_L: 2 DFT stages {g_dft:6.1f} us each + twiddle_transpose {g_tt:6.1f} us")
+    print(f"B={B:3d} [Python loop, wall]    analysis {t_an*1e3:8.1f} us | synthesis(+gather) {t_sy*1e3:8.1f} us | rfft_L {t_fft*1e3:8.1f} us")
