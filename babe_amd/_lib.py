@@ -106,9 +106,19 @@ def prof_slot_names():
     return [L.babe_prof_slot_name(i).decode() for i in range(L.babe_prof_nslots())]
 
 
+_prof_on = False
+
+
 def prof_enable(on):
     """Measurement hook (include/babe_hip.h): HIP-event timing of every launch, tallied per kernel slot."""
+    global _prof_on
+    _prof_on = bool(on)
     lib().babe_prof_enable(int(bool(on)))
+
+
+def prof_enabled():
+    """True while the measurement hook is on (its HIP events cannot be part of a captured graph)."""
+    return _prof_on
 
 
 def prof_read():

@@ -157,7 +157,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
     MAX_LANES = int(os.environ.get("BABE_UNET_STREAMS", "2"))
 
     def _get_lanes(self, B):
-        n = min(B, self.MAX_LANES)
+        n = min(B, self.MAX_LANES) if self.concurrent_lanes_ok else 1      # (bf16: one stream, see concurrent_lanes_ok)
         if n <= 1:
             return None
         if getattr(self, "_lanes", None) is None or len(self._lanes) != n:
@@ -199,7 +199,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
     # KNOWN ISSUE (round 3): with precision='bf16' two evaluation chains running concurrently on two streams occasionally
     # corrupt one clip (tools/tmp-free repro: tests/test_gpu_unet_full.py bf16 B=4; about one run in four; the fp32 and
     # single-stream runs are bit-stable) - a timing-dependent hazard inside the pipelined bf16 conv kernel that only shows
-    # under contention.  Until it is found the sampler keeps bf16 networks on ONE stream.
+    # under contention.  Until it is found bf16 networks run on ONE stream: the sampler puts the whole batch on a single
+    # lane (its HIP graphs still apply) and the network does not fork its own streams either.
     @property
     def concurrent_lanes_ok(self):
         return self.precision != "bf16"
