@@ -221,24 +221,41 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
         const float k3 = fsel(ps, 0x3f800000u, 0x40000000u, 0x40a00000u);        // 1 2 5
         const float x0 = fsel(ps, 0u, 0u, 0x40800000u), za = fsel(ps, 0x3f800000u, 0x3f800000u, 0u);
         const float x5 = fsel(ps, 0u, 0u, 0x3f800000u), ye = za;
+        // rows 1-4 of the patch: every pass
         float xh[6];                                      // row r: left sample in the first lane of a DPP row, right one in the last
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int r = 1; r < 5; ++r)
             asm("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(xh[r]) : "v"(hsrc), "v"(xhl), "n"(32 * r));
         // hipcc does not know that the statements above complete asynchronously: every later use of xh[] (register copies
         // included) is made to depend on this wait
-        asm("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]), "+v"(xh[5]));
+        asm("s_waitcnt lgkmcnt(0)" : "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]));
         float Ea[6], Eb[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             float d[6];
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+            for (int r = 1; r < 5; ++r)
                 d[r] = j == 0 ? dpp_shr1(xh[r], xv[r][3]) : (j == 5 ? dpp_shl1(xh[r], xv[r][0]) : xv[r][j - 1]);
             const float e = d[4] - k2 * d[2];
             const float o = k3 * d[3] - k1 * d[1];
-            Ea[j] = x0 * d[0] + (za * o + e);
-            Eb[j] = x5 * d[5] + (ye * e - o);
+            Ea[j] = za * o + e;
+            Eb[j] = ye * e - o;
+        }
+        // rows 0 and 5: the last pass only (x0 = 4, x5 = 1; their coefficients are 0 in the other two).  A wave-uniform
+        // branch around 2 ds_bpermute + 4 DPP moves + 12 FMAs - a seventh of the slab's vector instructions, and every one
+        // of them costs matrix-pipe time (the fp32 MFMA does not co-issue with the vector ALU).  It only touches transform
+        // temporaries: no accumulator is live-modified across it, so hipcc has nothing to copy at the merge.
+        if (ps == 2) {
+            asm("ds_bpermute_b32 %0, %1, %2" : "=v"(xh[0]) : "v"(hsrc), "v"(xhl));
+            asm("ds_bpermute_b32 %0, %1, %2 offset:160" : "=v"(xh[5]) : "v"(hsrc), "v"(xhl));
+            asm("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[5]));
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d0 = j == 0 ? dpp_shr1(xh[0], xv[0][3]) : (j == 5 ? dpp_shl1(xh[0], xv[0][0]) : xv[0][j - 1]);
+                const float d5 = j == 0 ? dpp_shr1(xh[5], xv[5][3]) : (j == 5 ? dpp_shl1(xh[5], xv[5][0]) : xv[5][j - 1]);
+                Ea[j] = x0 * d0 + Ea[j];
+                Eb[j] = x5 * d5 + Eb[j];
+            }
         }
         if (HAS_ISC) {
 #pragma unroll
