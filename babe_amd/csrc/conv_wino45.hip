@@ -57,7 +57,7 @@ constexpr unsigned OOBH = 0xC0000000u;     // invalid offsets start here: +-(a s
 #ifndef BABE_W45_NUM_VGPR
 #define BABE_W45_NUM_VGPR 128
 #endif
-template <bool HAS_ISC>
+template <bool HAS_ISC, bool PADC>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM_VGPR))) void conv_wino45_kernel(babe_conv_args a, Wino45Geom g, const float* __restrict__ wq) {
 #if __HIP_DEVICE_COMPILE__
     constexpr int NTH = 512, KC = 8, BN = 64, NU = 64;
@@ -71,10 +71,16 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave & 3, uw = wave >> 2;
+    // (cw, uw): waves w and w + 4 share a SIMD; they get channel tiles cw and cw ^ 2, so that on a tile whose upper 32 output
+    // channels are padding (Cout = 96: the second tile of every 96-channel layer) each SIMD hosts ONE wave with matrix work
+    // - the waves of the padded half skip their MFMAs and operand reads (wave-uniform), and the tile costs its transforms +
+    // half its MFMAs instead of a full tile
+    const int uw = wave >> 2, cw = (wave + 2 * uw) & 3;
     const int l15 = lane & 15, lk = lane >> 4;
     const int b = blockIdx.z;
     const int co0 = blockIdx.y * BN;
+    // PADC (launches whose last channel tile is padded): does this wave's 16-channel tile hold any real channel?
+    const bool mact = !PADC || co0 + cw * 16 < a.Cout;   // wave-uniform; compile-time true without PADC
     const int tile_t = blockIdx.x % g.tiles_t;
     const int rest = blockIdx.x / g.tiles_t;
     const int grp = rest % g.groups;
@@ -325,12 +331,12 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
     int rb = 0;                                   // ring slot of the slab being multiplied
     int pM = 0, cM = 0;                           // slab being multiplied (for the pass boundaries)
 #define MFMA_GRP(c, pg)                                                                                               \
-    if (!(ABL & 2)) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+    if (!(ABL & 2) && mact) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
         acc[0][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][0][i], acc[0][4 * (pg) + i], 0, 0, 0); \
         acc[1][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][1][i], acc[1][4 * (pg) + i], 0, 0, 0); \
     }
 #define READ_GRP(c, base, ks, pg)                                                   \
-    if (!(ABL & 4) || j == 0) {                                                     \
+    if ((!(ABL & 4) || j == 0) && mact) {                                           \
         av[c] = (base)[aoff + (ks) * 4 * BN * 3 + (pg)];                            \
         bv[c][0] = (base)[boff + (ks) * 4 * NU * 3 + (pg)];                         \
         bv[c][1] = (base)[boff + (ks) * 4 * NU * 3 + 16 * 3 + (pg)];                \
@@ -563,7 +569,11 @@ extern "C" int babe_conv2d_wino45_preferred(const babe_conv_args* ap) {
     const int groups = ((n + 1) / 2 + 3) / 4;
     const double u_rows = (double)n / (8.0 * groups);
     const double u_t = (double)a.T / (64.0 * ((a.T + 63) / 64));
-    const double u_c = (double)a.Cout / (64.0 * ((a.Cout + 63) / 64));
+    // channel tiles: a tile whose waves partly hold padding still pays its transforms (~0.4 of a tile, measured share of the
+    // vector work) but only the MFMAs of the waves with real channels (PADC variant of the kernel)
+    const int full = a.Cout / 64, rem = a.Cout % 64;
+    const double tiles_cost = full + (rem ? 0.4 + 0.6 * ((rem + 15) / 16) / 4.0 : 0.0);
+    const double u_c = (double)a.Cout / (64.0 * tiles_cost);
     return (u_rows >= 0.8 && u_t >= 0.875 && u_c >= 0.875) ? 1 : 0;
 }
 
@@ -583,10 +593,16 @@ extern "C" int babe_conv2d_wino45(const babe_conv_args* ap, const float* w_wino4
     dim3 grid(g.tiles_t * g.groups * a.dil, g.CoutP / 64, a.B);
     const size_t lds = 3 * (size_t)(8 * 64 * 3 + 8 * 64 * 3) * 16;           // 144 KB
     static std::atomic<unsigned long long> attr_done{0};
-    if (babe_lds_optin(attr_done, {reinterpret_cast<const void*>(&conv_wino45_kernel<true>),
-                                   reinterpret_cast<const void*>(&conv_wino45_kernel<false>)}, (int)lds) == hipSuccess) {
-        if (a.in_scale) hipLaunchKernelGGL((conv_wino45_kernel<true>), grid, dim3(512), lds, s, a, g, w_wino45);
-        else hipLaunchKernelGGL((conv_wino45_kernel<false>), grid, dim3(512), lds, s, a, g, w_wino45);
+    // PADC variant: the last channel tile has whole 16-channel wave tiles of padding (Cout = 96: two of four)
+    const bool padc = g.CoutP - a.Cout >= 16;
+    if (babe_lds_optin(attr_done, {reinterpret_cast<const void*>(&conv_wino45_kernel<true, false>),
+                                   reinterpret_cast<const void*>(&conv_wino45_kernel<false, false>),
+                                   reinterpret_cast<const void*>(&conv_wino45_kernel<true, true>),
+                                   reinterpret_cast<const void*>(&conv_wino45_kernel<false, true>)}, (int)lds) == hipSuccess) {
+        if (a.in_scale && padc) hipLaunchKernelGGL((conv_wino45_kernel<true, true>), grid, dim3(512), lds, s, a, g, w_wino45);
+        else if (a.in_scale) hipLaunchKernelGGL((conv_wino45_kernel<true, false>), grid, dim3(512), lds, s, a, g, w_wino45);
+        else if (padc) hipLaunchKernelGGL((conv_wino45_kernel<false, true>), grid, dim3(512), lds, s, a, g, w_wino45);
+        else hipLaunchKernelGGL((conv_wino45_kernel<false, false>), grid, dim3(512), lds, s, a, g, w_wino45);
     }
     BABE_LAUNCH_CHECK();
     return BABE_OK;
