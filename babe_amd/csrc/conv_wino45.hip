@@ -44,7 +44,24 @@ namespace {
 
 struct Wino45Geom {
     int CinP, CoutP, tiles_t, groups;
+    int tsh;      // tile shape: 4 >> tsh row pairs x (64 << tsh) time steps (the 64 units = 4 segments of 16; tsh = 0, 1, 2)
 };
+
+// Tile shape of a launch: segments (16 time units = 64 steps of one row pair) are dealt as (4 >> tsh) row pairs x (1 << tsh)
+// time blocks.  Chosen per launch for the fullest tiles: 10 rows per residue class are 5 pairs = 62.5 % of two 4-pair
+// tiles but 100 % of five 1-pair x 256-step tiles; 12 rows (6 pairs) fill three 2-pair x 128-step tiles.
+static inline double wino45_fill(const babe_conv_args& a, int tsh) {
+    const int n = (a.F + a.dil - 1) / a.dil;                 // rows per residue class
+    const int ppt = 4 >> tsh, tlen = 64 << tsh;
+    const int groups = ((n + 1) / 2 + ppt - 1) / ppt;
+    return ((double)n / (2.0 * ppt * groups)) * ((double)a.T / ((double)tlen * ((a.T + tlen - 1) / tlen)));
+}
+static inline int wino45_best_tsh(const babe_conv_args& a) {
+    int best = 0;
+    for (int t = 1; t <= 2; ++t)
+        if (wino45_fill(a, t) > wino45_fill(a, best) + 1e-9) best = t;
+    return best;
+}
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr unsigned OOBH = 0xC0000000u;     // invalid offsets start here: +-(a source view < 1 GiB) stays >= 2^31
@@ -85,7 +102,8 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
     const int rest = blockIdx.x / g.tiles_t;
     const int grp = rest % g.groups;
     const int cls = rest / g.groups;                    // residue class of the tile's rows (mod dil)
-    const int t0 = tile_t * 64;
+    const int t0 = tile_t * (64 << g.tsh);
+    const int ppt = 4 >> g.tsh, tbm = (1 << g.tsh) - 1;   // row pairs per tile, mask of the time-block index of a segment
     const int nci = g.CinP / KC;
     const int nslab = 3 * nci;
 
@@ -103,12 +121,13 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
     // paid in matrix-pipe time.  Hence: the channel and slab part of a load address travels in the SCALAR offset of the buffer
     // instruction (one input channel per wave), the per-lane part is a loop constant, coefficients are SGPRs, neighbour
     // samples come by DPP, and the slab body is one straight line (branches made hipcc shuffle 100+ registers per slab).
+    // segment q = lane >> 4 (a 16-lane DPP row): row pair q >> tsh of the tile, time block q & tbm
     const int s_tu = lane & 15, s_rp = lane >> 4;
-    const int s_t = t0 + 4 * s_tu;
-    const int s_fa = cls + 2 * (grp * 4 + s_rp) * a.dil;             // first output row of the pair
+    const int s_t = t0 + 64 * (s_rp & tbm) + 4 * s_tu;
+    const int s_fa = cls + 2 * (grp * ppt + (s_rp >> g.tsh)) * a.dil;             // first output row of the pair
     // Neighbour samples t-1 and t+4 come from the adjacent lanes (same row, tu -+ 1) by DPP row shifts; only the first lane of
     // a 16-lane DPP row needs t-1 from memory and only the last one t+4.  ONE dword load per slab fetches all 48 of them for
-    // the wave - lane L < 48 loads the sample of (row L >> 3, row pair (L >> 1) & 3, side L & 1) - and ds_bpermute hands
+    // the wave - lane L < 48 loads the sample of (row L >> 3, segment (L >> 1) & 3, side L & 1) - and ds_bpermute hands
     // each to the lane that needs it.  A vector-memory instruction costs about 8 ns of CU time next to fp32 MFMAs whether it
     // moves 1 KB or nothing (ablations in DESIGN.md 8), so their NUMBER is what the staging path minimises.
     unsigned er[6];                                                     // byte offset of (row r, t), or OOBH
@@ -121,8 +140,8 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
     unsigned ehalo = OOBH;
     {
         const int hr = lane >> 3, hg = (lane >> 1) & 3, hs = lane & 1;
-        const int fr = cls + 2 * (grp * 4 + hg) * a.dil + (hr - 2) * a.dil;
-        const int th = hs ? t0 + 64 : t0 - 1;
+        const int fr = cls + 2 * (grp * ppt + (hg >> g.tsh)) * a.dil + (hr - 2) * a.dil;
+        const int th = t0 + 64 * (hg & tbm) + (hs ? 64 : -1);
         if (lane < 48 && fr >= 0 && fr < a.F && th >= 0 && th < a.T) ehalo = (unsigned)((fr * a.T + th) * 4);
     }
     // bpermute source (byte index) of row 0 for this lane: its row pair's left sample, or the right one for the last lane of
@@ -427,11 +446,11 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
 
     // ---- output: rows fa (from M_0) and fa + dil (from M_5), time transform A4^T; lane = (unit l15, channels 4 lk .. 4 lk + 3)
     const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
-    const int t = t0 + 4 * l15;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int rp = uw * 2 + i;
-        const int fa = cls + 2 * (grp * 4 + rp) * a.dil;
+        const int rp = uw * 2 + i;                                   // segment
+        const int t = t0 + 64 * (rp & tbm) + 4 * l15;
+        const int fa = cls + 2 * (grp * ppt + (rp >> g.tsh)) * a.dil;
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
             const int f = fa + row * a.dil;
@@ -557,24 +576,21 @@ extern "C" int babe_conv2d_wino45_supported(const babe_conv_args* ap) {
     return 1;
 }
 
-/* 1 if the nested kernel is also the FASTER choice (what the dispatcher asks).  Tiles are 64 output channels x (4 row pairs of
- * one residue class) x 64 time steps; the kernel is worth its 0.6x matrix work only while the tiles are reasonably full
- * (measured 1.25-1.3x over conv_wino4p on full tiles): channels and time steps at least 7/8 used, row-pair slots at least
- * 80 % (7 rows per class = 4 pairs, one half empty: 87.5 %; 10 rows per class = 5 pairs in 2 tiles: 62.5 %, left to
- * conv_wino4p). */
+/* 1 if the nested kernel is also the FASTER choice (what the dispatcher asks).  Tiles are 64 output channels x 64 units, the
+ * units dealt as 4 / 2 / 1 row pairs of one residue class x 64 / 128 / 256 time steps (best fill per launch); the kernel is
+ * worth its 0.6x matrix work only while the tiles are reasonably full (measured 1.25-1.3x over conv_wino4p on full tiles):
+ * row-pair slots x time steps at least 80 % used (7 rows per class = 4 pairs, one half empty: 87.5 %; 6 rows per class at
+ * T = 128: 75 % in every shape, left to conv_wino4p), channels at least 7/8 of the (cost-weighted) channel tiles. */
 extern "C" int babe_conv2d_wino45_preferred(const babe_conv_args* ap) {
     if (!babe_conv2d_wino45_supported(ap)) return 0;
     const babe_conv_args& a = *ap;
-    const int n = (a.F + a.dil - 1) / a.dil;                 // rows per residue class
-    const int groups = ((n + 1) / 2 + 3) / 4;
-    const double u_rows = (double)n / (8.0 * groups);
-    const double u_t = (double)a.T / (64.0 * ((a.T + 63) / 64));
+    const double u_rt = wino45_fill(a, wino45_best_tsh(a));      // rows x time steps, best of the three tile shapes
     // channel tiles: a tile whose waves partly hold padding still pays its transforms (~0.4 of a tile, measured share of the
     // vector work) but only the MFMAs of the waves with real channels (PADC variant of the kernel)
     const int full = a.Cout / 64, rem = a.Cout % 64;
     const double tiles_cost = full + (rem ? 0.4 + 0.6 * ((rem + 15) / 16) / 4.0 : 0.0);
     const double u_c = (double)a.Cout / (64.0 * tiles_cost);
-    return (u_rows >= 0.8 && u_t >= 0.875 && u_c >= 0.875) ? 1 : 0;
+    return (u_rt >= 0.8 && u_c >= 0.875) ? 1 : 0;
 }
 
 extern "C" int babe_conv2d_wino45(const babe_conv_args* ap, const float* w_wino45, void* stream) {
@@ -584,9 +600,10 @@ extern "C" int babe_conv2d_wino45(const babe_conv_args* ap, const float* w_wino4
     Wino45Geom g;
     g.CinP = (a.Cin + 7) / 8 * 8;
     g.CoutP = (a.Cout + 63) / 64 * 64;
-    g.tiles_t = cdiv(a.T, 64);
+    g.tsh = wino45_best_tsh(a);
+    g.tiles_t = cdiv(a.T, 64 << g.tsh);
     const int n = cdiv(a.F, a.dil);                  // rows per residue class (at most)
-    g.groups = cdiv(cdiv(n, 2), 4);                  // 4 row pairs per tile
+    g.groups = cdiv(cdiv(n, 2), 4 >> g.tsh);         // 4 >> tsh row pairs per tile
     hipStream_t s = (hipStream_t)stream;
     const double flops = babe_conv_flops(a);         // 36 multiplies per 8 outputs instead of 120: 0.3 of the direct count
     BabeProfScope prof(BABE_SLOT_CONV53_WINO45, babe_conv_bytes(a), flops, flops * 0.3, stream);
