@@ -43,18 +43,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 struct Wino45Geom {
-    int CinP, CoutP, tiles_t, groups;
+    int CinP, CoutP, tiles_t, groups;      // groups: tiles along the flattened (residue class, row pair) list
+    int npairs;   // row pairs per residue class (ceil(ceil(F / dil) / 2))
     int tsh;      // tile shape: 4 >> tsh row pairs x (64 << tsh) time steps (the 64 units = 4 segments of 16; tsh = 0, 1, 2)
 };
 
 // Tile shape of a launch: segments (16 time units = 64 steps of one row pair) are dealt as (4 >> tsh) row pairs x (1 << tsh)
-// time blocks.  Chosen per launch for the fullest tiles: 10 rows per residue class are 5 pairs = 62.5 % of two 4-pair
-// tiles but 100 % of five 1-pair x 256-step tiles; 12 rows (6 pairs) fill three 2-pair x 128-step tiles.
+// time blocks.  Chosen per launch for the fullest tiles (time: T = 128 fills 64- and 128-step tiles, not 256-step ones; rows:
+// the pairs of all residue classes are one list, so only its last tile and the odd row of a class are lost).
 static inline double wino45_fill(const babe_conv_args& a, int tsh) {
-    const int n = (a.F + a.dil - 1) / a.dil;                 // rows per residue class
     const int ppt = 4 >> tsh, tlen = 64 << tsh;
-    const int groups = ((n + 1) / 2 + ppt - 1) / ppt;
-    return ((double)n / (2.0 * ppt * groups)) * ((double)a.T / ((double)tlen * ((a.T + tlen - 1) / tlen)));
+    const long npall = (long)a.dil * (((a.F + a.dil - 1) / a.dil + 1) / 2);     // pairs of all residue classes (one list)
+    const long tiles = (npall + ppt - 1) / ppt;
+    return ((double)a.F / (2.0 * ppt * tiles)) * ((double)a.T / ((double)tlen * ((a.T + tlen - 1) / tlen)));
 }
 static inline int wino45_best_tsh(const babe_conv_args& a) {
     int best = 0;
@@ -100,10 +101,18 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
     const bool mact = !PADC || co0 + cw * 16 < a.Cout;   // wave-uniform; compile-time true without PADC
     const int tile_t = blockIdx.x % g.tiles_t;
     const int rest = blockIdx.x / g.tiles_t;
-    const int grp = rest % g.groups;
-    const int cls = rest / g.groups;                    // residue class of the tile's rows (mod dil)
+    // Row pairs of ALL residue classes form one list, pair P = class * npairs + p (rows class + 2p dil, class + (2p+1) dil);
+    // a tile takes ppt consecutive entries - a class boundary may fall inside a tile (the segments of a tile are independent:
+    // 6 rows per class = 3 pairs filled 3 of 4 slots when tiles stayed inside a class).  Beyond the list: row >= F.
+    const int P0 = rest * (4 >> g.tsh);
+    const int npall = a.dil * g.npairs;
+    auto pair_row = [&](int lp) __attribute__((always_inline)) {        // first output row of local pair lp of this tile
+        const int P = P0 + lp;
+        const int c = P / g.npairs;
+        return P < npall ? c + 2 * (P - c * g.npairs) * a.dil : a.F + 4 * a.dil;
+    };
     const int t0 = tile_t * (64 << g.tsh);
-    const int ppt = 4 >> g.tsh, tbm = (1 << g.tsh) - 1;   // row pairs per tile, mask of the time-block index of a segment
+    const int tbm = (1 << g.tsh) - 1;                     // mask of the time-block index of a segment
     const int nci = g.CinP / KC;
     const int nslab = 3 * nci;
 
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
     // segment q = lane >> 4 (a 16-lane DPP row): row pair q >> tsh of the tile, time block q & tbm
     const int s_tu = lane & 15, s_rp = lane >> 4;
     const int s_t = t0 + 64 * (s_rp & tbm) + 4 * s_tu;
-    const int s_fa = cls + 2 * (grp * ppt + (s_rp >> g.tsh)) * a.dil;             // first output row of the pair
+    const int s_fa = pair_row(s_rp >> g.tsh);                        // first output row of the pair
     // Neighbour samples t-1 and t+4 come from the adjacent lanes (same row, tu -+ 1) by DPP row shifts; only the first lane of
     // a 16-lane DPP row needs t-1 from memory and only the last one t+4.  ONE dword load per slab fetches all 48 of them for
     // the wave - lane L < 48 loads the sample of (row L >> 3, segment (L >> 1) & 3, side L & 1) - and ds_bpermute hands
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
     unsigned ehalo = OOBH;
     {
         const int hr = lane >> 3, hg = (lane >> 1) & 3, hs = lane & 1;
-        const int fr = cls + 2 * (grp * ppt + (hg >> g.tsh)) * a.dil + (hr - 2) * a.dil;
+        const int fr = pair_row(hg >> g.tsh) + (hr - 2) * a.dil;
         const int th = t0 + 64 * (hg & tbm) + (hs ? 64 : -1);
         if (lane < 48 && fr >= 0 && fr < a.F && th >= 0 && th < a.T) ehalo = (unsigned)((fr * a.T + th) * 4);
     }
@@ -450,7 +459,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
     for (int i = 0; i < 2; ++i) {
         const int rp = uw * 2 + i;                                   // segment
         const int t = t0 + 64 * (rp & tbm) + 4 * l15;
-        const int fa = cls + 2 * (grp * ppt + (rp >> g.tsh)) * a.dil;
+        const int fa = pair_row(rp >> g.tsh);
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
             const int f = fa + row * a.dil;
@@ -603,11 +612,12 @@ extern "C" int babe_conv2d_wino45(const babe_conv_args* ap, const float* w_wino4
     g.tsh = wino45_best_tsh(a);
     g.tiles_t = cdiv(a.T, 64 << g.tsh);
     const int n = cdiv(a.F, a.dil);                  // rows per residue class (at most)
-    g.groups = cdiv(cdiv(n, 2), 4 >> g.tsh);         // 4 >> tsh row pairs per tile
+    g.npairs = cdiv(n, 2);
+    g.groups = cdiv(a.dil * g.npairs, 4 >> g.tsh);   // 4 >> tsh row pairs per tile, from the list of all classes' pairs
     hipStream_t s = (hipStream_t)stream;
     const double flops = babe_conv_flops(a);         // 36 multiplies per 8 outputs instead of 120: 0.3 of the direct count
     BabeProfScope prof(BABE_SLOT_CONV53_WINO45, babe_conv_bytes(a), flops, flops * 0.3, stream);
-    dim3 grid(g.tiles_t * g.groups * a.dil, g.CoutP / 64, a.B);
+    dim3 grid(g.tiles_t * g.groups, g.CoutP / 64, a.B);
     const size_t lds = 3 * (size_t)(8 * 64 * 3 + 8 * 64 * 3) * 16;           // 144 KB
     static std::atomic<unsigned long long> attr_done{0};
     // PADC variant: the last channel tile has whole 16-channel wave tiles of padding (Cout = 96: two of four)
