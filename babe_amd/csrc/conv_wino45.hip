@@ -493,6 +493,362 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// WIDE variant (128 / 256 output channels): tile = 128 output channels x 32 units (2 segments of 16 time units: 2 row pairs
+// x 64 steps, or 1 row pair x 128 steps), wave w = 16-channel tile w x both segments: the same 2 x 12 accumulators.
+// Why: the 2D input transform is recomputed by every channel tile of a layer and its ~100 vector instructions per wave
+// and slab are paid in matrix-pipe time (fp32 MFMA and the vector ALU do not co-issue).  With 128-channel tiles a layer
+// has half as many channel tiles, and the transform runs over SIXTEEN input channels at a time (thread = (ci, unit), all
+// 512 threads busy) once per TWO 8-channel weight slabs: half the transform instructions per MFMA.
+//   LDS 144 KB: activations X[2] of 16 ci x 32 units x 48 B = 24 KB each, weights W[2] of 8 ci x 128 co x 48 B = 48 KB.
+//   step k (8 ci, 48 MFMAs per wave): MFMAs on X[S & 1] (S = k / 2) half k & 1 with W[k & 1]; at its top the DMA of
+//   W(k + 1) goes to the buffer step k - 1 released; EVEN steps also transform super-slab S + 1 from the staging registers
+//   into X[(S + 1) & 1] (free since the barrier of step k - 1) and then issue the loads of super-slab S + 2 into the same
+//   registers - two steps before their transform; ODD steps have no staging work.  One barrier per step.
+template <bool HAS_ISC>
+__global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, Wino45Geom g, const float* __restrict__ wq) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int NTH = 512, KC = 8, KS = 16, BN = 128, NU = 32;
+    constexpr int XSZ = KS * NU * 3;                    // float4 per activation super-slab (16 ci x 32 units x 12 floats)
+    constexpr int WSZ = KC * BN * 3;                    // float4 per weight slab
+    constexpr int WJ = WSZ / NTH;                       // 6 weight float4 per thread and step
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    f32x4* smem = reinterpret_cast<f32x4*>(smem_f);
+    f32x4* const Xb = smem;                             // X[2]
+    f32x4* const Wb = smem + 2 * XSZ;                   // W[2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.z;
+    const int co0 = blockIdx.y * BN;
+    const int tile_t = blockIdx.x % g.tiles_t;
+    const int rest = blockIdx.x / g.tiles_t;
+    const int t0 = tile_t * (64 << g.tsh);
+    const int tbm = (1 << g.tsh) - 1;
+    const int P0 = rest * (2 >> g.tsh);
+    const int npall = a.dil * g.npairs;
+    auto pair_row = [&](int lp) __attribute__((always_inline)) {
+        const int P = P0 + lp;
+        const int c = P / g.npairs;
+        return P < npall ? c + 2 * (P - c * g.npairs) * a.dil : a.F + 4 * a.dil;
+    };
+    const int nk = 3 * (g.CinP / KC);                   // steps (8-channel weight slabs)
+
+    const float* p1 = a.in + (long)b * a.in_bs;
+    const int cs1 = (int)a.in_cs;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p1, 0, a.Cin * cs1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, 3 * g.CinP * g.CoutP * 48, 0x00020000);
+
+    // ---- staging constants: thread = (ci = 2 wave + (lane >> 5), unit = lane & 31 = segment (lane >> 4) & 1, time unit lane & 15).
+    // The wave's first channel travels in the scalar offset, the second one is a per-lane loop constant (+ one channel stride).
+    const int s_tu = lane & 15, s_sg = (lane >> 4) & 1, s_ch = lane >> 5;
+    const int s_t = t0 + 64 * (s_sg & tbm) + 4 * s_tu;
+    const int s_fa = pair_row(s_sg >> g.tsh);
+    const unsigned chb = (unsigned)(s_ch * cs1 * 4);
+    unsigned er[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int fr = s_fa + (r - 2) * a.dil;
+        const bool ok = fr >= 0 && fr < a.F && s_t < a.T;
+        er[r] = ok ? (unsigned)((fr * a.T + s_t) * 4) + chb : OOBH;
+    }
+    // halo: lane L < 48 loads the sample of (row L >> 3, channel (L >> 2) & 1, segment (L >> 1) & 1, side L & 1)
+    unsigned ehalo = OOBH;
+    {
+        const int hr = lane >> 3, hc = (lane >> 2) & 1, hg = (lane >> 1) & 1, hs = lane & 1;
+        const int fr = pair_row(hg >> g.tsh) + (hr - 2) * a.dil;
+        const int th = t0 + 64 * (hg & tbm) + (hs ? 64 : -1);
+        if (lane < 48 && fr >= 0 && fr < a.F && th >= 0 && th < a.T) ehalo = (unsigned)((fr * a.T + th) * 4 + hc * cs1 * 4);
+    }
+    const int hsrc = (4 * s_ch + 2 * s_sg + (s_tu == 15 ? 1 : 0)) * 4;     // row r adds 32 bytes (8 lanes per row)
+    const int xlds = tid * 3;                                              // (ci_local * 32 + unit) * 3 with ci_local * 32 + unit = tid
+    const int wvo = lane * 16;
+
+    f32x4 acc[2][12];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 12; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 xvm[4], xve[2];
+    float xhl = 0.f, xsc = 1.f;
+    int pS = 0;                                           // pass of the data held in the staging registers
+    xve[0] = xve[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto issue_rows = [&](int ci0, int r0, int r1) __attribute__((always_inline)) {
+        const int so = (ci0 + 2 * wave) * cs1 * 4;
+#pragma unroll
+        for (int r = 1; r < 5; ++r) {
+            if (r < r0 || r >= r1) continue;
+            xvm[r - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[r], so, 0));
+        }
+    };
+    auto issue_halo = [&](int ci0) __attribute__((always_inline)) {
+        const int so = (ci0 + 2 * wave) * cs1 * 4;
+        xhl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ehalo, so, 0));
+    };
+    auto issue_isc = [&](int ci0) __attribute__((always_inline)) {
+        if (HAS_ISC) {
+            const float s0 = a.in_scale[(long)b * a.Cin + ci0 + 2 * wave], s1 = a.in_scale[(long)b * a.Cin + ci0 + 2 * wave + 1];
+            xsc = s_ch ? s1 : s0;
+        }
+    };
+    auto issue_edge = [&](int ps, int ci0) __attribute__((always_inline)) {
+        const int so = (ci0 + 2 * wave) * cs1 * 4;
+        const unsigned edge = ps == 2 ? 0u : OOBH;
+        xve[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[0] | edge, so, 0));
+        xve[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[5] | edge, so, 0));
+    };
+    auto dpp_shr1 = [](float old, float src) __attribute__((always_inline)) {
+        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+        return old;
+    };
+    auto dpp_shl1 = [](float old, float src) __attribute__((always_inline)) {
+        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+        return old;
+    };
+    auto fsel = [](int ps, unsigned c0, unsigned c1, unsigned c2) __attribute__((always_inline)) {
+        return __builtin_bit_cast(float, ps == 0 ? c0 : (ps == 1 ? c1 : c2));
+    };
+    auto tt = [](const float (&E)[6], float (&U)[6]) {
+        const float e = E[4] - 4.f * E[2], o = E[3] - 4.f * E[1];
+        const float e2 = E[4] - E[2], o2 = E[3] - E[1];
+        U[0] = 4.f * E[0] + (E[4] - 5.f * E[2]);
+        U[1] = e + o;
+        U[2] = e - o;
+        U[3] = e2 + 2.f * o2;
+        U[4] = e2 - 2.f * o2;
+        U[5] = 4.f * E[1] + (E[5] - 5.f * E[3]);
+    };
+    // (same arithmetic, in the same order, as conv_wino45_kernel::store_act: the two kernels give bit-identical products)
+    auto store_act = [&](f32x4* buf) __attribute__((always_inline)) {
+        const int ps = pS;
+        const f32x4 xv[6] = {xve[0], xvm[0], xvm[1], xvm[2], xvm[3], xve[1]};
+        const float k2 = fsel(ps, 0x40800000u, 0x3f800000u, 0x40a00000u);
+        const float k1 = fsel(ps, 0x40800000u, 0x40000000u, 0x40800000u);
+        const float k3 = fsel(ps, 0x3f800000u, 0x40000000u, 0x40a00000u);
+        const float x0 = fsel(ps, 0u, 0u, 0x40800000u), za = fsel(ps, 0x3f800000u, 0x3f800000u, 0u);
+        const float x5 = fsel(ps, 0u, 0u, 0x3f800000u), ye = za;
+        float xh[6];
+#pragma unroll
+        for (int r = 1; r < 5; ++r)
+            asm("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(xh[r]) : "v"(hsrc), "v"(xhl), "n"(32 * r));
+        asm("s_waitcnt lgkmcnt(0)" : "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]));
+        float Ea[6], Eb[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float d[6];
+#pragma unroll
+            for (int r = 1; r < 5; ++r)
+                d[r] = j == 0 ? dpp_shr1(xh[r], xv[r][3]) : (j == 5 ? dpp_shl1(xh[r], xv[r][0]) : xv[r][j - 1]);
+            const float e = d[4] - k2 * d[2];
+            const float o = k3 * d[3] - k1 * d[1];
+            Ea[j] = za * o + e;
+            Eb[j] = ye * e - o;
+        }
+        if (ps == 2) {
+            asm("ds_bpermute_b32 %0, %1, %2" : "=v"(xh[0]) : "v"(hsrc), "v"(xhl));
+            asm("ds_bpermute_b32 %0, %1, %2 offset:160" : "=v"(xh[5]) : "v"(hsrc), "v"(xhl));
+            asm("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[5]));
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d0 = j == 0 ? dpp_shr1(xh[0], xv[0][3]) : (j == 5 ? dpp_shl1(xh[0], xv[0][0]) : xv[0][j - 1]);
+                const float d5 = j == 0 ? dpp_shr1(xh[5], xv[5][3]) : (j == 5 ? dpp_shl1(xh[5], xv[5][0]) : xv[5][j - 1]);
+                Ea[j] = x0 * d0 + Ea[j];
+                Eb[j] = x5 * d5 + Eb[j];
+            }
+        }
+        if (HAS_ISC) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                Ea[j] *= xsc;
+                Eb[j] *= xsc;
+            }
+        }
+        float Ua[6], Ub[6];
+        tt(Ea, Ua);
+        tt(Eb, Ub);
+        buf[xlds] = f32x4{Ua[0], Ua[1], Ua[2], Ua[3]};
+        buf[xlds + 1] = f32x4{Ua[4], Ua[5], Ub[0], Ub[1]};
+        buf[xlds + 2] = f32x4{Ub[2], Ub[3], Ub[4], Ub[5]};
+    };
+    // weight slab [8 ci][128 co][12] = 48 chunks of 1 KB, 6 per input channel; wave w moves chunks w, w + 8, ..., w + 40
+    auto dma_w = [&](int ps, int ci0, f32x4* buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jj = 0; jj < WJ; ++jj) {
+            const int c = wave + 8 * jj;
+            const int so = ((ps * g.CinP + ci0 + c / 6) * g.CoutP + co0) * 48 + (c % 6) * 1024;     // bytes, scalar
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(buf + c * 64), 16, wvo, so, 0, 0);
+        }
+    };
+    auto advance = [&](int& ps, int& ci0, int step) __attribute__((always_inline)) {    // next (super-)slab, clamped at the last one
+        int nc = ci0 + step, np = ps;
+        if (nc >= g.CinP) {
+            nc = 0;
+            ++np;
+        }
+        if (np <= 2) {
+            ps = np;
+            ci0 = nc;
+        }
+    };
+
+    // operand addresses (float4 units): A in a weight slab, B in an activation super-slab (half h adds 8 * NU * 3)
+    const int aoff = (lk * BN + cw * 16 + l15) * 3;
+    const int boff = (lk * NU + l15) * 3;
+
+    // ---- prologue: super-slab 0 transformed into X[0], loads of super-slab 1 in flight, weight slab 0 in W[0]
+    int pA = 0, cA = 0;                          // next super-slab to load
+    int pW = 0, cW = 0;                          // next weight slab to DMA
+    issue_edge(pA, cA);
+    issue_rows(cA, 1, 5);
+    issue_halo(cA);
+    issue_isc(cA);
+    pS = pA;
+    dma_w(pW, cW, Wb);
+    advance(pW, cW, KC);
+    store_act(Xb);
+    advance(pA, cA, KS);
+    issue_edge(pA, cA);
+    issue_rows(cA, 1, 5);
+    issue_halo(cA);
+    issue_isc(cA);
+    pS = pA;
+    __syncthreads();
+
+    f32x4 av, bv[2];
+    int pM = 0, cM = 0;                           // weight slab being multiplied (for the pass boundaries)
+#define W_MFMA(pg)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+        acc[0][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[0][i], acc[0][4 * (pg) + i], 0, 0, 0); \
+        acc[1][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[1][i], acc[1][4 * (pg) + i], 0, 0, 0); \
+    }
+#define W_READ(ks, pg)                                              \
+    av = Ws[aoff + (ks) * 4 * BN * 3 + (pg)];                       \
+    bv[0] = Xs[boff + (ks) * 4 * NU * 3 + (pg)];                    \
+    bv[1] = Xs[boff + (ks) * 4 * NU * 3 + 16 * 3 + (pg)];
+#define W_GROUP(ks, pg, pgm)                   \
+    W_READ(ks, pg)                             \
+    __builtin_amdgcn_sched_barrier(0);         \
+    W_MFMA(pgm)                                \
+    __builtin_amdgcn_sched_barrier(0);
+    for (int k = 0; k < nk; k += 2) {
+        // ---- even step: S = k / 2, half 0
+        {
+            const f32x4* Xs = Xb + ((k >> 1) & 1) * XSZ;
+            const f32x4* Ws = Wb;                                    // W[k & 1] = W[0]
+            f32x4* Xw = Xb + (((k >> 1) + 1) & 1) * XSZ;
+            dma_w(pW, cW, Wb + WSZ);                                 // weight slab k + 1 -> W[1]
+            advance(pW, cW, KC);
+            __builtin_amdgcn_sched_barrier(0);
+            W_READ(0, 0)
+            store_act(Xw);                                           // super-slab S + 1
+            advance(pA, cA, KS);
+            issue_isc(cA);
+            pS = pA;
+            __builtin_amdgcn_sched_barrier(0);
+            issue_edge(pA, cA);                                      // loads of super-slab S + 2: two steps ahead
+            __builtin_amdgcn_sched_barrier(0);
+            issue_rows(cA, 1, 3);
+            W_MFMA(0)
+            __builtin_amdgcn_sched_barrier(0);
+            issue_rows(cA, 3, 5);
+            W_GROUP(0, 1, 1)
+            issue_halo(cA);
+            W_GROUP(0, 2, 2)
+            W_GROUP(1, 0, 0)
+            W_GROUP(1, 1, 1)
+            W_GROUP(1, 2, 2)
+            // weight slab k + 1 landed (6 DMAs, older than the 7 loads of this step), X[(S + 1) & 1] written
+            asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)");
+            __builtin_amdgcn_s_barrier();
+        }
+        // ---- odd step: half 1 of the same super-slab, W[1]
+        {
+            const f32x4* Xs = Xb + ((k >> 1) & 1) * XSZ + KC * NU * 3;
+            const f32x4* Ws = Wb + WSZ;
+            dma_w(pW, cW, Wb);                                       // weight slab k + 2 -> W[0]
+            advance(pW, cW, KC);
+            __builtin_amdgcn_sched_barrier(0);
+            W_READ(0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            W_MFMA(0)
+            __builtin_amdgcn_sched_barrier(0);
+            W_GROUP(0, 1, 1)
+            W_GROUP(0, 2, 2)
+            W_GROUP(1, 0, 0)
+            W_GROUP(1, 1, 1)
+            W_GROUP(1, 2, 2)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+            __builtin_amdgcn_s_barrier();
+        }
+        cM += KS;
+        if (cM >= g.CinP) {
+            cM = 0;
+            if (pM == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 6; ++p) {
+                        const f32x4 m1 = acc[i][p], m2 = acc[i][6 + p];
+                        acc[i][p] = 0.75f * m1 + 0.25f * m2;
+                        acc[i][6 + p] = 0.25f * m1 + 0.75f * m2;
+                    }
+            } else if (pM == 1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 6; ++p) {
+                        const f32x4 m3 = acc[i][p], m4 = acc[i][6 + p];
+                        acc[i][p] = m3 + m4;
+                        acc[i][6 + p] = 2.f * (m3 - m4);
+                    }
+            }
+            ++pM;
+        }
+    }
+#undef W_MFMA
+#undef W_READ
+#undef W_GROUP
+
+    // ---- output (as conv_wino45_kernel): lane = (unit l15 of segment i, channels 4 lk .. 4 lk + 3 of the wave's 16)
+    const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = t0 + 64 * (i & tbm) + 4 * l15;
+        const int fa = pair_row(i >> g.tsh);
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            const int f = fa + row * a.dil;
+            const bool pv = f < a.F && t < a.T;
+            const long sp = pv ? (long)f * a.T + t : 0;
+            float os[4];
+            f32x4 rr[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = co0 + cw * 16 + 4 * lk + kk;           // < Cout: Cout % 128 == 0
+                os[kk] = has_os ? a.oscale[b * a.Cout + co] : 1.f;
+                rr[kk] = has_res ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)co * a.res_cs + sp)
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = co0 + cw * 16 + 4 * lk + kk;
+                const float m0 = acc[i][6 * row + 0][kk], m1 = acc[i][6 * row + 1][kk], m2 = acc[i][6 * row + 2][kk];
+                const float m3 = acc[i][6 * row + 3][kk], m4 = acc[i][6 * row + 4][kk], m5 = acc[i][6 * row + 5][kk];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                f32x4 y = {m0 + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + m5};
+                const float sc = a.alpha * os[kk];
+                y = y * sc + a.rbeta * rr[kk];
+                if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
+            }
+        }
+    }
+#endif
+}
+
 // dst [3 passes][CinP][CoutP][12]: pass ps holds frequency phases (1,2), (3,4), (0,5); entry 6*fpl + tp
 __global__ void pack_wino45_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int tf, int CinP,
                                    int CoutP, long total) {
@@ -585,6 +941,22 @@ extern "C" int babe_conv2d_wino45_supported(const babe_conv_args* ap) {
     return 1;
 }
 
+// wide variant (128-channel tiles x 32 units): eligible shapes and its tile shape (2 row pairs x 64 steps or 1 x 128)
+static inline double wino45w_fill(const babe_conv_args& a, int tsh) {
+    const int ppt = 2 >> tsh, tlen = 64 << tsh;
+    const long npall = (long)a.dil * (((a.F + a.dil - 1) / a.dil + 1) / 2);
+    const long tiles = (npall + ppt - 1) / ppt;
+    return ((double)a.F / (2.0 * ppt * tiles)) * ((double)a.T / ((double)tlen * ((a.T + tlen - 1) / tlen)));
+}
+static inline int wino45w_ok(const babe_conv_args& a) {
+    static const char* ov = getenv("BABE_CONV_WINO45W");
+    if (ov && ov[0] == '0') return 0;
+    if (a.Cout % 128 != 0 || a.Cin % 16 != 0) return 0;
+    const double f0 = wino45w_fill(a, 0), f1 = wino45w_fill(a, 1);
+    // as full as the 64-channel tiling of the same launch (which has 64 units to deal)
+    return (f0 > f1 ? f0 : f1) + 1e-9 >= wino45_fill(a, wino45_best_tsh(a)) ? 1 : 0;
+}
+
 /* 1 if the nested kernel is also the FASTER choice (what the dispatcher asks).  Tiles are 64 output channels x 64 units, the
  * units dealt as 4 / 2 / 1 row pairs of one residue class x 64 / 128 / 256 time steps (best fill per launch); the kernel is
  * worth its 0.6x matrix work only while the tiles are reasonably full (measured 1.25-1.3x over conv_wino4p on full tiles):
@@ -617,6 +989,22 @@ extern "C" int babe_conv2d_wino45(const babe_conv_args* ap, const float* w_wino4
     hipStream_t s = (hipStream_t)stream;
     const double flops = babe_conv_flops(a);         // 36 multiplies per 8 outputs instead of 120: 0.3 of the direct count
     BabeProfScope prof(BABE_SLOT_CONV53_WINO45, babe_conv_bytes(a), flops, flops * 0.3, stream);
+    if (wino45w_ok(a)) {
+        g.tsh = wino45w_fill(a, 1) > wino45w_fill(a, 0) + 1e-9 ? 1 : 0;
+        g.tiles_t = cdiv(a.T, 64 << g.tsh);
+        g.npairs = cdiv(cdiv(a.F, a.dil), 2);
+        g.groups = cdiv(a.dil * g.npairs, 2 >> g.tsh);
+        dim3 gridw(g.tiles_t * g.groups, g.CoutP / 128, a.B);
+        const size_t ldsw = (size_t)(2 * 16 * 32 * 3 + 2 * 8 * 128 * 3) * 16;       // 144 KB
+        static std::atomic<unsigned long long> attr_w{0};
+        if (babe_lds_optin(attr_w, {reinterpret_cast<const void*>(&conv_wino45w_kernel<true>),
+                                    reinterpret_cast<const void*>(&conv_wino45w_kernel<false>)}, (int)ldsw) == hipSuccess) {
+            if (a.in_scale) hipLaunchKernelGGL((conv_wino45w_kernel<true>), gridw, dim3(512), ldsw, s, a, g, w_wino45);
+            else hipLaunchKernelGGL((conv_wino45w_kernel<false>), gridw, dim3(512), ldsw, s, a, g, w_wino45);
+        }
+        BABE_LAUNCH_CHECK();
+        return BABE_OK;
+    }
     dim3 grid(g.tiles_t * g.groups, g.CoutP / 64, a.B);
     const size_t lds = 3 * (size_t)(8 * 64 * 3 + 8 * 64 * 3) * 16;           // 144 KB
     static std::atomic<unsigned long long> attr_done{0};
