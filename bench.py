@@ -125,7 +125,7 @@ PMC_TRAFFIC_FILE = "r03_conv_traffic.json"
 
 
 def conv_traffic(precision):
-    """HBM-side bytes per launch of the dominant conv kernel (conv_wino45_kernel) from the committed PMC passes (rocprofv3 cannot run inside the bench; the
+    """HBM-side bytes per launch of the dominant conv kernel (conv_wino45_kernel + conv_wino45w_kernel) from the committed PMC passes (rocprofv3 cannot run inside the bench; the
     passes are separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this command, profiles/README.md)."""
     path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     if precision != "f32" or not os.path.exists(path):
@@ -335,9 +335,10 @@ def main():
             tr = conv_traffic(a.precision)
             roof = {
                 "bound": "mfma",
-                "kernel": (("conv_wino45_kernel: nested Winograd F(2,5) along frequency x F(4,3) along time, fp32 "
-                            "v_mfma_f32_16x16x4_f32 (executes 0.3 of the algorithmic flops), fwd + input-VJP launches of the UNet; "
-                            "the layers it does not take run on conv_wino4p_kernel (all_conv_kernels)" if dom == "conv53_wino45" else
+                "kernel": (("conv_wino45_kernel / conv_wino45w_kernel (64- / 128-channel tiles of the same algorithm; one "
+                            "measurement slot): nested Winograd F(2,5) along frequency x F(4,3) along time, fp32 "
+                            "v_mfma_f32_16x16x4_f32 (executes 0.3 of the algorithmic flops), fwd + input-VJP launches of every "
+                            "(5,3) layer of the UNet with >= 64 channels (all_conv_kernels has the rest)" if dom == "conv53_wino45" else
                             "conv_wino4p_kernel: pipelined Winograd F(4,3)-along-time (5,3) conv, fp32 v_mfma_f32_32x32x2_f32, "
                             "fwd + input-VJP launches of the UNet") if a.precision == "f32" else
                            "%s (v_mfma_f32_32x32x16_bf16; %s products per k-block)"
