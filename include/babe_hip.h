@@ -89,6 +89,9 @@ long babe_conv_packed_size_wino4(int Cout, int Cin, int KH, int transpose_flip);
  * about 3.4x the F(4,3) kernel's (2-3e-6 relative).  Replaces the same F.conv2d call (cqtdiff+.py:85) and its input-VJP.
  * w_wino45 from babe_conv_pack_weights_wino45: [3 passes][ceil8(Cin)][ceil64(Cout)][12].  Needs KH x KW = 5 x 3,
  * T % 4 == 0, T >= 64, Cin % 16 == 0, Cout > 32, 16-byte aligned in/out/res rows, ONE source (no in2), views < 1 GiB. */
+/* Two tilings behind the one entry point: 64-channel tiles x 64 units (any Cout; a PADC variant skips the MFMAs of waves whose
+ * channels are padding, e.g. Cout = 96) and, for Cout % 128 == 0, 128-channel tiles x 32 units that transform 16 input
+ * channels at a time (BABE_CONV_WINO45W=0 turns the second one off).  Same arithmetic in the same order in both. */
 int babe_conv2d_wino45(const babe_conv_args* a, const float* w_wino45, void* stream);
 int babe_conv2d_wino45_supported(const babe_conv_args* a);   /* the kernel CAN run this problem */
 int babe_conv2d_wino45_preferred(const babe_conv_args* a);   /* ... and its tiles are full enough to beat the F(4,3) kernel */
