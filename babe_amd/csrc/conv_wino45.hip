@@ -505,13 +505,17 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45_NUM
 //   W(k + 1) goes to the buffer step k - 1 released; EVEN steps also transform super-slab S + 1 from the staging registers
 //   into X[(S + 1) & 1] (free since the barrier of step k - 1) and then issue the loads of super-slab S + 2 into the same
 //   registers - two steps before their transform; ODD steps have no staging work.  One barrier per step.
-template <bool HAS_ISC>
+// BN = 96 (the 96-channel layers): 6 channel tiles x 2 segments = 12 (tile, segment) items for 8 waves - waves 0-3 take a
+// channel tile with both segments, waves 4-7 one (tile, segment) each, so that the two waves of a SIMD (w, w + 4) hold three
+// items: every SIMD does 3/4 of the matrix work of a 128-channel tile, none idles.
+template <bool HAS_ISC, int BN>
 __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, Wino45Geom g, const float* __restrict__ wq) {
 #if __HIP_DEVICE_COMPILE__
-    constexpr int NTH = 512, KC = 8, KS = 16, BN = 128, NU = 32;
+    constexpr int NTH = 512, KC = 8, KS = 16, NU = 32;
+    static_assert(BN == 128 || BN == 96, "tile width");
     constexpr int XSZ = KS * NU * 3;                    // float4 per activation super-slab (16 ci x 32 units x 12 floats)
     constexpr int WSZ = KC * BN * 3;                    // float4 per weight slab
-    constexpr int WJ = WSZ / NTH;                       // 6 weight float4 per thread and step
+    constexpr int WJ = (WSZ + NTH - 1) / NTH;           // 6 (5 for BN = 96: 36 chunks) weight float4 per thread and step
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     f32x4* smem = reinterpret_cast<f32x4*>(smem_f);
     f32x4* const Xb = smem;                             // X[2]
@@ -520,7 +524,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave;
+    // items of this wave: channel tile cw, segment sg0 (and segment 1 when `two`)
+    const int cw = (BN == 128 || wave < 4) ? wave : 4 + ((wave - 4) >> 1);
+    const int sg0 = (BN == 128 || wave < 4) ? 0 : (wave - 4) & 1;
+    const bool two = BN == 128 || wave < 4;              // wave-uniform
     const int l15 = lane & 15, lk = lane >> 4;
     const int b = blockIdx.z;
     const int co0 = blockIdx.y * BN;
@@ -566,6 +573,17 @@ __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, 
     const int hsrc = (4 * s_ch + 2 * s_sg + (s_tu == 15 ? 1 : 0)) * 4;     // row r adds 32 bytes (8 lanes per row)
     const int xlds = tid * 3;                                              // (ci_local * 32 + unit) * 3 with ci_local * 32 + unit = tid
     const int wvo = lane * 16;
+    // BN = 96: a weight row (96 co x 48 B) is not a whole number of 1 KB chunks: per-lane source offsets (slot s of the slab
+    // image [8 ci][96 co][3] lies at ci * CoutP * 48 + (s % 288) * 16 of the slab's first row), chunks beyond the 36 read nothing
+    unsigned wvl[BN == 96 ? WJ : 1];
+    if (BN == 96) {
+#pragma unroll
+        for (int jj = 0; jj < WJ; ++jj) {
+            const int sl = (wave + 8 * jj) * 64 + lane;
+            const int ci = sl / (BN * 3);
+            wvl[BN == 96 ? jj : 0] = wave + 8 * jj < WSZ / 64 ? (unsigned)(ci * g.CoutP * 48 + (sl - ci * BN * 3) * 16) : OOBH;
+        }
+    }
 
     f32x4 acc[2][12];
 #pragma unroll
@@ -679,8 +697,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, 
 #pragma unroll
         for (int jj = 0; jj < WJ; ++jj) {
             const int c = wave + 8 * jj;
-            const int so = ((ps * g.CinP + ci0 + c / 6) * g.CoutP + co0) * 48 + (c % 6) * 1024;     // bytes, scalar
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(buf + c * 64), 16, wvo, so, 0, 0);
+            if constexpr (BN == 128) {
+                const int so = ((ps * g.CinP + ci0 + c / 6) * g.CoutP + co0) * 48 + (c % 6) * 1024;     // bytes, scalar
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(buf + c * 64), 16, wvo, so, 0, 0);
+            } else {
+                const int so = ((ps * g.CinP + ci0) * g.CoutP + co0) * 48;
+                if (c < WSZ / 64)              // wave-uniform: the image has 36 chunks, waves 4-7 move four of them
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(buf + c * 64), 16, wvl[jj], so, 0, 0);
+            }
         }
     };
     auto advance = [&](int& ps, int& ci0, int step) __attribute__((always_inline)) {    // next (super-)slab, clamped at the last one
@@ -697,7 +721,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, 
 
     // operand addresses (float4 units): A in a weight slab, B in an activation super-slab (half h adds 8 * NU * 3)
     const int aoff = (lk * BN + cw * 16 + l15) * 3;
-    const int boff = (lk * NU + l15) * 3;
+    const int boff = (lk * NU + sg0 * 16 + l15) * 3;
 
     // ---- prologue: super-slab 0 transformed into X[0], loads of super-slab 1 in flight, weight slab 0 in W[0]
     int pA = 0, cA = 0;                          // next super-slab to load
@@ -723,12 +747,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, 
 #define W_MFMA(pg)                                                                                   \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
         acc[0][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[0][i], acc[0][4 * (pg) + i], 0, 0, 0); \
-        acc[1][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[1][i], acc[1][4 * (pg) + i], 0, 0, 0); \
+        if (two) acc[1][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[1][i], acc[1][4 * (pg) + i], 0, 0, 0); \
     }
 #define W_READ(ks, pg)                                              \
     av = Ws[aoff + (ks) * 4 * BN * 3 + (pg)];                       \
     bv[0] = Xs[boff + (ks) * 4 * NU * 3 + (pg)];                    \
-    bv[1] = Xs[boff + (ks) * 4 * NU * 3 + 16 * 3 + (pg)];
+    if (two) bv[1] = Xs[boff + (ks) * 4 * NU * 3 + 16 * 3 + (pg)];
 #define W_GROUP(ks, pg, pgm)                   \
     W_READ(ks, pg)                             \
     __builtin_amdgcn_sched_barrier(0);         \
@@ -762,7 +786,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, 
             W_GROUP(1, 1, 1)
             W_GROUP(1, 2, 2)
             // weight slab k + 1 landed (6 DMAs, older than the 7 loads of this step), X[(S + 1) & 1] written
-            asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)");
+            asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)");               /* (BN = 96: 5 DMAs; the count is of the loads after them) */
             __builtin_amdgcn_s_barrier();
         }
         // ---- odd step: half 1 of the same super-slab, W[1]
@@ -817,8 +841,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, 
     const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int t = t0 + 64 * (i & tbm) + 4 * l15;
-        const int fa = pair_row(i >> g.tsh);
+        if (i == 1 && !two) break;
+        const int sg = i == 0 ? sg0 : 1;                              // segment of item i
+        const int t = t0 + 64 * (sg & tbm) + 4 * l15;
+        const int fa = pair_row(sg >> g.tsh);
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
             const int f = fa + row * a.dil;
@@ -828,7 +854,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, 
             f32x4 rr[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const int co = co0 + cw * 16 + 4 * lk + kk;           // < Cout: Cout % 128 == 0
+                const int co = co0 + cw * 16 + 4 * lk + kk;           // < Cout: Cout % BN == 0
                 os[kk] = has_os ? a.oscale[b * a.Cout + co] : 1.f;
                 rr[kk] = has_res ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)co * a.res_cs + sp)
                                  : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -951,7 +977,7 @@ static inline double wino45w_fill(const babe_conv_args& a, int tsh) {
 static inline int wino45w_ok(const babe_conv_args& a) {
     static const char* ov = getenv("BABE_CONV_WINO45W");
     if (ov && ov[0] == '0') return 0;
-    if (a.Cout % 128 != 0 || a.Cin % 16 != 0) return 0;
+    if ((a.Cout % 128 != 0 && a.Cout % 96 != 0) || a.Cin % 16 != 0) return 0;
     const double f0 = wino45w_fill(a, 0), f1 = wino45w_fill(a, 1);
     // as full as the 64-channel tiling of the same launch (which has 64 units to deal)
     return (f0 > f1 ? f0 : f1) + 1e-9 >= wino45_fill(a, wino45_best_tsh(a)) ? 1 : 0;
@@ -994,13 +1020,22 @@ extern "C" int babe_conv2d_wino45(const babe_conv_args* ap, const float* w_wino4
         g.tiles_t = cdiv(a.T, 64 << g.tsh);
         g.npairs = cdiv(cdiv(a.F, a.dil), 2);
         g.groups = cdiv(a.dil * g.npairs, 2 >> g.tsh);
-        dim3 gridw(g.tiles_t * g.groups, g.CoutP / 128, a.B);
-        const size_t ldsw = (size_t)(2 * 16 * 32 * 3 + 2 * 8 * 128 * 3) * 16;       // 144 KB
+        const int bnw = a.Cout % 128 == 0 ? 128 : 96;
+        dim3 gridw(g.tiles_t * g.groups, a.Cout / bnw, a.B);
+        const size_t ldsw = (size_t)(2 * 16 * 32 * 3 + 2 * 8 * bnw * 3) * 16;       // 144 KB (120 KB for 96-channel tiles)
         static std::atomic<unsigned long long> attr_w{0};
-        if (babe_lds_optin(attr_w, {reinterpret_cast<const void*>(&conv_wino45w_kernel<true>),
-                                    reinterpret_cast<const void*>(&conv_wino45w_kernel<false>)}, (int)ldsw) == hipSuccess) {
-            if (a.in_scale) hipLaunchKernelGGL((conv_wino45w_kernel<true>), gridw, dim3(512), ldsw, s, a, g, w_wino45);
-            else hipLaunchKernelGGL((conv_wino45w_kernel<false>), gridw, dim3(512), ldsw, s, a, g, w_wino45);
+        if (babe_lds_optin(attr_w, {reinterpret_cast<const void*>(&conv_wino45w_kernel<true, 128>),
+                                    reinterpret_cast<const void*>(&conv_wino45w_kernel<false, 128>),
+                                    reinterpret_cast<const void*>(&conv_wino45w_kernel<true, 96>),
+                                    reinterpret_cast<const void*>(&conv_wino45w_kernel<false, 96>)},
+                           (int)((size_t)(2 * 16 * 32 * 3 + 2 * 8 * 128 * 3) * 16)) == hipSuccess) {
+            if (bnw == 128) {
+                if (a.in_scale) hipLaunchKernelGGL((conv_wino45w_kernel<true, 128>), gridw, dim3(512), ldsw, s, a, g, w_wino45);
+                else hipLaunchKernelGGL((conv_wino45w_kernel<false, 128>), gridw, dim3(512), ldsw, s, a, g, w_wino45);
+            } else {
+                if (a.in_scale) hipLaunchKernelGGL((conv_wino45w_kernel<true, 96>), gridw, dim3(512), ldsw, s, a, g, w_wino45);
+                else hipLaunchKernelGGL((conv_wino45w_kernel<false, 96>), gridw, dim3(512), ldsw, s, a, g, w_wino45);
+            }
         }
         BABE_LAUNCH_CHECK();
         return BABE_OK;
