@@ -505,6 +505,9 @@ def test_gelu_one_exponential_form_is_within_fp32_roundoff_of_erf(ops):
     (1, 128, 0, 128, 24, 192, 16),     # dilation > rows per class / 2
     (2, 48, 0, 72, 20, 68, 1),         # channel counts that are not multiples of 64
     (1, 128, 0, 64, 448, 64, 64),      # the benchmark's deepest geometry: 7 rows per class
+    (2, 256, 0, 128, 32, 128, 2),      # wide kernel (128-channel tiles), B = 2, 1 row pair x 128 steps
+    (1, 96, 0, 192, 48, 256, 1),       # wide kernel with two 96-channel tiles (second one at channel offset 96)
+    (1, 128, 0, 256, 12, 68, 4),       # wide kernel, two 128-channel tiles, ragged T, 3 rows per class (odd)
 ])
 def test_conv2d_nested_winograd_vs_float64(ops, B, C1, C2, Cout, Fq, T, dil):
     """csrc/conv_wino45.hip - F(2,5) along frequency x F(4,3) along time in three accumulator-carried passes - against the

@@ -1,5 +1,7 @@
 out=gpurun_out/r3r; mkdir -p $out
-timeout 600 python3 -m pytest tests/test_gpu_ops.py -m gpu -q -k "nested or wino" -s > $out/t.log 2>&1; grep "nested Winograd" $out/t.log | cut -c1-150; tail -2 $out/t.log
-SHAPES=enc1.H,enc2.H0,enc2.H3,dec2.H0,dec3.H0,dec3.H4 timeout 300 python3 tools/conv_shapes_bench.py > $out/shapes_w.txt 2>&1
-SHAPES=enc1.H,enc2.H0,enc2.H3,dec2.H0,dec3.H0,dec3.H4 BABE_CONV_WINO45W=0 timeout 300 python3 tools/conv_shapes_bench.py > $out/shapes_n.txt 2>&1
-paste $out/shapes_w.txt $out/shapes_n.txt | cut -c1-95,170-200
+timeout 900 python3 -m pytest tests/test_gpu_unet_full.py tests/test_gpu_sampler.py -m gpu -q -x > $out/t2.log 2>&1; tail -3 $out/t2.log
+python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > $out/bench_w.json 2> $out/bench_w.err
+BABE_CONV_WINO45W=0 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > $out/bench_n.json 2> $out/bench_n.err
+for f in w n; do python3 -c "
+import json
+d=json.loads(open('$out/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'])"; done
