@@ -10,11 +10,12 @@ H = st.design_filter(torch.tensor([[3000.0], [-30.0]], device=dev))
 y = st.apply_filter(x, H)
 stats = st.mag_stats(st.stft(x), st.stft(y))
 cfg = make_fit_cfg(tol=(0.0, 0.0))          # never converges early: max_iter iterations
-p0 = torch.tensor([[[1000.0], [-20.0]]], device=dev)
+K = int(os.environ.get("K", "5"))
+p0 = torch.tensor([[[1000.0 * (i + 1) for i in range(K)], [-20.0 - 5.0 * i for i in range(K)]]], device=dev)
 for _ in range(2):
     p = p0.clone(); nit = st.filter_fit(stats, p, cfg)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 p = p0.clone()
 e0.record(); nit = st.filter_fit(stats, p, cfg); e1.record(); torch.cuda.synchronize()
-print(f"filter_fit: {e0.elapsed_time(e1)*1e3:.0f} us for {int(nit[0])} iterations -> fc={float(p[0,0,0]):.2f} Hz A={float(p[0,1,0]):.4f} dB")
+print(f"filter_fit (K={K}): {e0.elapsed_time(e1)*1e3:.0f} us for {int(nit[0])} iterations -> fc={[round(float(v), 2) for v in p[0,0]]} Hz A={[round(float(v), 4) for v in p[0,1]]} dB")
