@@ -496,6 +496,25 @@ def test_gelu_one_exponential_form_is_within_fp32_roundoff_of_erf(ops):
     assert err < 1e-6
 
 
+def test_nested_winograd_wide_and_64_channel_tiles_are_bit_identical(ops):
+    """conv_wino45w (128- / 96-channel tiles, transform over 16 input channels at a time) and conv_wino45 (64-channel tiles)
+    do the same arithmetic in the same order: a 128- (192-) channel conv on the wide kernel equals, bit for bit, the same
+    conv done as two (three) 64-channel convs on the 64-channel-tile kernel."""
+    from babe_amd._lib import dispatch_counts
+    for Cout, Cin, Fq, T, dil in ((128, 128, 48, 128, 2), (192, 96, 32, 256, 1)):
+        g = torch.Generator().manual_seed(Cout + Cin)
+        x = torch.randn(2, Cin, Fq, T, generator=g).cuda()
+        w = (torch.randn(Cout, Cin, 5, 3, generator=g) / math.sqrt(Cin * 15)).cuda()
+        out = torch.empty(2, Cout, Fq, T, device="cuda")
+        dispatch_counts(reset=True)
+        ops.conv2d(x, ops.PackedConv(w), out, dil=dil, force_nested=True)
+        parts = torch.empty_like(out)
+        for c0 in range(0, Cout, 64):
+            ops.conv2d(x, ops.PackedConv(w[c0:c0 + 64].contiguous()), parts[:, c0:c0 + 64], dil=dil, force_nested=True)
+        assert dispatch_counts()["conv53_wino45"] == 1 + Cout // 64
+        assert torch.equal(out, parts), float((out - parts).abs().max())
+
+
 @pytest.mark.parametrize("B,C1,C2,Cout,Fq,T,dil", [
     (1, 64, 0, 64, 64, 128, 1),        # whole tiles
     (2, 64, 0, 64, 64, 64, 2),         # two residue classes, T = one tile
