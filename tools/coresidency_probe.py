@@ -38,6 +38,9 @@ partners = {
     "f32 wino45 256ch": mkconv("f32", 256, 256, 448, 64, 5, 2, "fwd"),
     "f32 conv11p 512->256": mkconv("f32", 512, 256, 448, 64, 1, 1, "fwd"),
 }
+sel = os.environ.get("PARTNERS")
+if sel:
+    partners = {k: v for k, v in partners.items() if any(t in k for t in sel.split(","))}
 sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
 for vn, vf in victims.items():
     ref = vf().clone(); torch.cuda.synchronize()
