@@ -9,11 +9,25 @@ OUT = os.path.join(HERE, "libbabe_hip.so")
 SOURCES = ["misc.hip", "conv.hip", "conv11p.hip", "conv_fewco.hip", "conv_bf16.hip", "conv_bf16p.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4p.hip", "conv_wino45.hip", "norm.hip", "resample.hip", "cqt.hip", "stft.hip", "sampler.hip", "denoiser.hip"]
 
 
-# per-source extra flags.  conv_wino45: hipcc's SLP vectoriser packs the input-transform arithmetic into v_pk_* instructions
-# and pays for it with ~35 register moves per K-slab; next to fp32 MFMAs every vector instruction costs matrix-pipe time
-# (tools/mfma_valu_coexec.hip: a v_pk_fma_f32 costs 1.6x a v_fma_f32, a v_mov as much as a v_fma): 207 instead of 245 vector
-# instructions per two slabs without it
-EXTRA_FLAGS = {"conv_wino45.hip": ["-fno-slp-vectorize"]}
+# Every source is built WITHOUT packed-fp32 instructions: no SLP vectoriser (-fno-slp-vectorize) and the target feature
+# packed-fp32-ops switched off (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32 are never selected, also not for
+# explicit float2 / float4 vector arithmetic).  Two reasons, both measured in round 3:
+#  * speed of the fp32-MFMA kernels: next to fp32 MFMAs every vector instruction costs matrix-pipe time
+#    (tools/mfma_valu_coexec.hip: a v_pk_fma_f32 costs 1.6x a v_fma_f32, a v_mov as much as a v_fma), and the vectoriser pays
+#    for its packed arithmetic with register moves: conv_wino45 207 instead of 245 vector instructions per two K-slabs;
+#  * CORRECTNESS next to the bf16 conv: kernels that contain packed-fp32 instructions (conv_fewco, the FFT's twiddle /
+#    transpose, epilogues with float4 arithmetic, ...) return slightly wrong sums - one of a thread's four outputs, half of
+#    the lanes, errors the size of a few product terms - when they run on a second stream beside conv_bf16p
+#    (v_mfma_f32_32x32x16_bf16): 25-30 of 30 runs in tools/coresidency_probe.py, about one two-lane bf16 sampler run in four.
+#    Alone they are exact.  Without the vectoriser only: 0 of 30 in the probe, 2 of 12 sampler runs still differ (explicit
+#    vector arithmetic still becomes v_pk_*); with packed-fp32-ops off as well - not one v_pk_ instruction in the library -
+#    0 of 16 two-lane bf16 sampler runs (tools/bf16_lanes_soak.py) and 0 of 30 in every pairing of the probe.  Neither an LDS
+#    canary nor hand-written v_pk_* chains beside the bf16 conv reproduce it (tools/lds_canary.hip), so the trigger is
+#    narrower than "any packed instruction" - but with none in the library the question does not arise.
+#    Whole-job throughput is unchanged (f32 1.794 vs 1.797, same box); bf16 runs its clips on two lanes again: 3.18 -> 3.68.
+# (The host pass prints "'-packed-fp32-ops' is not a recognized feature for this target (ignoring feature)": filtered below.)
+COMMON_FLAGS = ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+EXTRA_FLAGS = {}
 
 
 def needs_build():
@@ -58,7 +72,7 @@ def _build_locked(force, verbose):
         if (not force) and os.path.exists(o) and os.path.getmtime(o) > max([os.path.getmtime(p), hdr_mtime]):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", p, "-o", o,
-               "-Wno-unused-result"] + EXTRA_FLAGS.get(src, [])
+               "-Wno-unused-result"] + COMMON_FLAGS + EXTRA_FLAGS.get(src, [])
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -68,8 +82,10 @@ def _build_locked(force, verbose):
         if pr.returncode != 0:
             failed = True
             print(f"--- {src} FAILED\n{out}", file=sys.stderr)
-        elif verbose and out.strip():
-            print(out)
+        elif verbose:
+            out = "\n".join(l for l in out.splitlines() if "packed-fp32-ops" not in l)
+            if out.strip():
+                print(out)
     if failed:
         raise RuntimeError("hipcc failed")
     tmp = OUT + f".tmp{os.getpid()}"

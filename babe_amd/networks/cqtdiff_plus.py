@@ -157,7 +157,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
     MAX_LANES = int(os.environ.get("BABE_UNET_STREAMS", "2"))
 
     def _get_lanes(self, B):
-        n = min(B, self.MAX_LANES) if self.concurrent_lanes_ok else 1      # (bf16: one stream, see concurrent_lanes_ok)
+        n = min(B, self.MAX_LANES) if self.concurrent_lanes_ok else 1      # (BABE_BF16_LANES=0: bf16 on one stream)
         if n <= 1:
             return None
         if getattr(self, "_lanes", None) is None or len(self._lanes) != n:
@@ -196,14 +196,13 @@ class Unet_CQT_oct_with_attention(nn.Module):
 
     # ---------------------------------------------------------------- raw (no autograd) interface
     supports_lanes = True
-    # KNOWN ISSUE (round 3): with precision='bf16' two evaluation chains running concurrently on two streams occasionally
-    # corrupt one clip (tools/tmp-free repro: tests/test_gpu_unet_full.py bf16 B=4; about one run in four; the fp32 and
-    # single-stream runs are bit-stable) - a timing-dependent hazard inside the pipelined bf16 conv kernel that only shows
-    # under contention.  Until it is found bf16 networks run on ONE stream: the sampler puts the whole batch on a single
-    # lane (its HIP graphs still apply) and the network does not fork its own streams either.
+    # (Round 3: with precision='bf16' two evaluation chains on two streams used to corrupt about one sampler run in four -
+    # kernels containing packed-fp32 instructions gave wrong sums beside the bf16 conv.  The library is built without any
+    # packed-fp32 instruction now, babe_amd/build.py, and the two-lane bf16 soak is clean; DESIGN.md 8.  BABE_BF16_LANES=0
+    # puts bf16 networks back on one stream.)
     @property
     def concurrent_lanes_ok(self):
-        return self.precision != "bf16"
+        return self.precision != "bf16" or os.environ.get("BABE_BF16_LANES", "1") != "0"
 
     def lane_engine(self, lane):
         """Engine state number `lane` (saved activations + scratch of its own over the shared packed weights): a caller that

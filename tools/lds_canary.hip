@@ -77,6 +77,11 @@ __device__ __forceinline__ cf2 pk_step(cf2 r, cf2 c, cf2 d) {
     asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(r), "v"(c));                       // (r.x c.x, r.x c.y)
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(u) : "v"(r), "v"(d), "v"(t));   // (r.x d.x + t.y, r.y d.y + t.x)
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(u), "v"(c), "v"(r));         // (u.x c.x + r.x, u.y c.x + r.y)
+    // the forms hipcc uses to build shifted pairs and to add with an inline constant
+    asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(u) : "v"(t), "v"(r));                          // (t.y, r.x)
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(t) : "v"(t), "v"(u));
+    asm volatile("v_pk_add_f32 %0, %1, 0 op_sel_hi:[1,0]" : "=v"(t) : "v"(t));
+    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(t), "v"(c));
     return t;
 }
 extern "C" __global__ void pk_canary_kernel(unsigned* out, int iters) {
