@@ -29,6 +29,62 @@ struct C11Geom {
     int CinP, CoutP, pt_log2, pr_log2, tiles_t;
 };
 
+// Epilogue through buffer descriptors: out = alpha*acc*oscale[b,co] + rbeta*res.  One per-lane byte offset per position
+// (out of range when the position is padding) + one scalar term per output channel; a channel beyond Cout lands beyond the
+// descriptor's size, so the hardware range check drops it - no per-element branches, no 64-bit address arithmetic, and
+// none of the 132-1228 bytes per lane of scratch the pointer-based shared epilogue (conv_common.h) needed at 256 registers.
+// With four K-slabs per tile (the 64-channel full-resolution layers) the epilogue is a quarter of the kernel.
+template <int NT, int WP>
+__device__ __forceinline__ void conv11p_epilogue(const babe_conv_args& a, f32x16 (&acc)[NT][WP], int b, int co0, int f0,
+                                                 int t0, int pt_log2, int wave, int l31, int h) {
+#if __HIP_DEVICE_COMPILE__
+    const int PT = 1 << pt_log2;
+    const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (long)b * a.out_bs), 0, (unsigned)(a.Cout * a.out_cs * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc((void*)(has_res ? a.res + (long)b * a.res_bs : a.out), 0,
+                                                                         has_res ? (unsigned)(a.Cout * a.res_cs * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)(has_os ? a.oscale + (long)b * a.Cout : a.out), 0,
+                                                                         has_os ? (unsigned)(a.Cout * 4) : 0u, 0x00020000);
+    const unsigned ocs = (unsigned)a.out_cs * 4u, rcs = (unsigned)a.res_cs * 4u;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        // output scales of this lane's 16 channels (channel = co0 + nt*32 + (r & 3) + 8*(r >> 2) + 4*h), once per row tile
+        float os[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = nt * 32 + (r & 3) + 8 * (r >> 2);
+            os[r] = has_os ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, (unsigned)(co0 + 4 * h + cl) * 4u, 0, 0)) * a.alpha
+                           : a.alpha;
+        }
+#pragma unroll
+        for (int wp = 0; wp < WP; ++wp) {
+            const int p = (wave * WP + wp) * 32 + l31;
+            const int f = f0 + (p >> pt_log2);
+            const int t = t0 + (p & (PT - 1));
+            const bool pv = f < a.F && t < a.T;
+            const unsigned sp = (unsigned)(f * a.T + t) * 4u;
+            const unsigned lo = pv ? (unsigned)(co0 + 4 * h) * ocs + sp : 0x80000000u;
+            const unsigned lr = pv ? (unsigned)(co0 + 4 * h) * rcs + sp : 0x80000000u;
+            float rv[16];
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = nt * 32 + (r & 3) + 8 * (r >> 2);
+                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr_, lr + (unsigned)cl * rcs, 0, 0));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = nt * 32 + (r & 3) + 8 * (r >> 2);
+                float v = acc[nt][wp][r] * os[r];
+                if (has_res) v += a.rbeta * rv[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), ro, lo + (unsigned)cl * ocs, 0, 0);
+            }
+        }
+    }
+#endif
+}
+
 // NPW = 32-position MFMA column tiles per wave: 2 (256 positions per workgroup, 2 workgroups per CU) or 1 (128 positions,
 // 3 per CU: finer tail quantisation for the launches with only a few hundred workgroups)
 template <int NT, int NPW, bool HAS_ISC>
@@ -174,7 +230,7 @@ __global__ __launch_bounds__(256, NPW == 2 ? 2 : 3) void conv11p_kernel(babe_con
         }
         rb = rn;
     }
-    conv_epilogue<NT, NPW>(a, acc, b, co0, f0, t0, g.pt_log2, wave, l31, h);
+    conv11p_epilogue<NT, NPW>(a, acc, b, co0, f0, t0, g.pt_log2, wave, l31, h);
 #endif
 }
 
@@ -214,6 +270,9 @@ int babe_conv11p_supported(const babe_conv_args& a, int nt) {
     const int split = a.in2 ? a.cin_split : a.Cin;
     if ((long)split * a.in_cs >= lim || (a.in2 && (long)(a.Cin - split) * a.in2_cs >= lim)) return 0;
     if ((long)((a.Cin + 7) / 8 * 8) * ((a.Cout + 31) / 32 * 32) >= lim) return 0;
+    // the epilogue addresses out / res of a batch item through buffer descriptors with 32-bit offsets
+    const long coP = (a.Cout + 31) / 32 * 32;
+    if (coP * a.out_cs >= lim || (a.res && coP * a.res_cs >= lim)) return 0;
     if ((long)a.F * a.T < 4096 && a.Cin < 256) return 0;     // tiny planes AND a short K loop: nothing to pipeline (the
                                                              // dense DFT stages, K ~ 2000 over a few hundred positions, qualify)
     return 1;
