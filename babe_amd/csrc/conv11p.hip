@@ -53,7 +53,7 @@ __device__ __forceinline__ void conv11p_epilogue(const babe_conv_args& a, f32x16
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int cl = nt * 32 + (r & 3) + 8 * (r >> 2);
-            os[r] = has_os ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, (unsigned)(co0 + 4 * h + cl) * 4u, 0, 0)) * a.alpha
+            os[r] = has_os ? __fmul_rn(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, (unsigned)(co0 + 4 * h + cl) * 4u, 0, 0)), a.alpha)
                            : a.alpha;
         }
 #pragma unroll
@@ -76,8 +76,10 @@ __device__ __forceinline__ void conv11p_epilogue(const babe_conv_args& a, f32x16
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cl = nt * 32 + (r & 3) + 8 * (r >> 2);
-                float v = acc[nt][wp][r] * os[r];
-                if (has_res) v += a.rbeta * rv[r];
+                // (explicit rounding points: left to -ffp-contract the 128- and 256-position instantiations fused different
+                // pairs of these three operations and gave results one ulp apart for the same input)
+                float v = __fmul_rn(acc[nt][wp][r], os[r]);
+                if (has_res) v = __builtin_fmaf(a.rbeta, rv[r], v);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), ro, lo + (unsigned)cl * ocs, 0, 0);
             }
         }
