@@ -875,6 +875,459 @@ __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// WIDE variant, second generation (round 4): same tile (BN output channels x 32 units), same arithmetic in the same order as
+// conv_wino45w_kernel (bit-identical results), different pipeline.  What the round-3 counters said about the first one: the
+// matrix pipe is busy 0.54-0.62 of the time, the vector ALU work accounts for ~0.1 more, and for the remaining ~0.3 BOTH waves
+// of a SIMD are parked.  Three causes, all structural:
+//  (1) ONE operand register set: a wave reads the operands of MFMA group g + 1 only after the last MFMA of group g has issued
+//      and then waits a full LDS latency; the two waves of a SIMD are released together by the step barrier, alternate their
+//      MFMAs and therefore reach their read-and-wait at the same time, every group (6 per step);
+//  (2) a barrier per 8-channel step, needed only because the weight slab is shared workgroup-wide in LDS - although in this
+//      tiling wave w is the ONLY reader of the weights of channel tile w;
+//  (3) all 8 waves issue their 6 weight DMAs back to back at the top of every step.
+// Here: (1) two operand sets - the reads of group g + 1 are issued before the MFMAs of group g; (2) WAVE-PRIVATE weights: every
+// wave DMAs exactly the 16-channel slice it multiplies with (4 input channels x 16 output channels x 48 B = 3 chunks of 1 KB
+// per slot, per-lane gather offsets) into its own part of a 4-slot ring and waits for it with a counted s_waitcnt - no barrier
+// for weights, three slots (72 MFMAs per wave, ~2 us) of DMA latency budget instead of one step; the only shared data are the
+// transformed activations X[2], written once per 16-channel super-slab: ONE barrier per 96 MFMAs per wave, placed before the
+// last MFMA group of the super-slab, whose operands are in registers by then, so that the first operand reads of the next
+// super-slab run behind those MFMAs; (3) one DMA instruction per MFMA group.  The halo samples' ds_bpermute are issued one
+// MFMA group before the transform that consumes them.  LDS: X[2] x 24 KB + ring 4 x 8 waves x 3 KB = 144 KB.
+// vmcnt bookkeeping (vector-memory operations complete in order).  Per super-slab and wave, in issue order:
+//   g0: D E E R R | g1: D R R | g2: D H | g3 .. g11: D          (D weight DMA chunk, E edge row, R row, H halo: 19 operations)
+// the DMAs of group 3i + j move chunk j of weight slot 4S + i + 3 into ring position (i + 3) & 3.  Operand reads of a new
+// slot are issued in the last group of the previous one: slot 1 at g2 (its last chunk was issued at g8 of the previous
+// super-slab: 13 younger operations), slot 2 at g5 (g11 of the previous one: 13), slot 3 at g8 (g2: 7), slot 0 of the next
+// super-slab at g11 (g5: 6).
+template <bool HAS_ISC, int BN>
+__global__ __launch_bounds__(512, 1) void conv_wino45x_kernel(babe_conv_args a, Wino45Geom g, const float* __restrict__ wq) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int KS = 16, KQ = 4, NU = 32;
+    static_assert(BN == 128 || BN == 96, "tile width");
+    constexpr int XSZ = KS * NU * 3;                    // float4 per activation super-slab (16 ci x 32 units x 12 floats)
+    constexpr int WWV = KQ * 16 * 3;                    // float4 per wave and ring slot (4 ci x 16 co x 12 floats = 3 KB)
+    constexpr int WSL = 8 * WWV;                        // float4 per ring slot (8 waves)
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    f32x4* smem = reinterpret_cast<f32x4*>(smem_f);
+    f32x4* const Xb = smem;                             // X[2]
+    f32x4* const Wb = smem + 2 * XSZ;                   // ring[4][8 waves][4 ci][16 co][3]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = (BN == 128 || wave < 4) ? wave : 4 + ((wave - 4) >> 1);
+    const int sg0 = (BN == 128 || wave < 4) ? 0 : (wave - 4) & 1;
+    const bool two = BN == 128 || wave < 4;              // wave-uniform
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.z;
+    const int co0 = blockIdx.y * BN;
+    const int tile_t = blockIdx.x % g.tiles_t;
+    const int rest = blockIdx.x / g.tiles_t;
+    const int t0 = tile_t * (64 << g.tsh);
+    const int tbm = (1 << g.tsh) - 1;
+    const int P0 = rest * (2 >> g.tsh);
+    const int npall = a.dil * g.npairs;
+    auto pair_row = [&](int lp) __attribute__((always_inline)) {
+        const int P = P0 + lp;
+        const int c = P / g.npairs;
+        return P < npall ? c + 2 * (P - c * g.npairs) * a.dil : a.F + 4 * a.dil;
+    };
+    const int NS = 3 * (g.CinP / KS);                   // super-slabs
+
+    const float* p1 = a.in + (long)b * a.in_bs;
+    const int cs1 = (int)a.in_cs;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p1, 0, a.Cin * cs1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, 3 * g.CinP * g.CoutP * 48, 0x00020000);
+
+    // ---- staging constants (as conv_wino45w_kernel): thread = (ci = 2 wave + (lane >> 5), unit = lane & 31)
+    const int s_tu = lane & 15, s_sg = (lane >> 4) & 1, s_ch = lane >> 5;
+    const int s_t = t0 + 64 * (s_sg & tbm) + 4 * s_tu;
+    const int s_fa = pair_row(s_sg >> g.tsh);
+    const unsigned chb = (unsigned)(s_ch * cs1 * 4);
+    unsigned er[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int fr = s_fa + (r - 2) * a.dil;
+        const bool ok = fr >= 0 && fr < a.F && s_t < a.T;
+        er[r] = ok ? (unsigned)((fr * a.T + s_t) * 4) + chb : OOBH;
+    }
+    unsigned ehalo = OOBH;
+    {
+        const int hr = lane >> 3, hc = (lane >> 2) & 1, hg = (lane >> 1) & 1, hs = lane & 1;
+        const int fr = pair_row(hg >> g.tsh) + (hr - 2) * a.dil;
+        const int th = t0 + 64 * (hg & tbm) + (hs ? 64 : -1);
+        if (lane < 48 && fr >= 0 && fr < a.F && th >= 0 && th < a.T) ehalo = (unsigned)((fr * a.T + th) * 4 + hc * cs1 * 4);
+    }
+    const int hsrc = (4 * s_ch + 2 * s_sg + (s_tu == 15 ? 1 : 0)) * 4;
+    const int xlds = tid * 3;
+    // weight DMA: chunk j of a slot = bytes [1024 j, 1024 j + 1024) of the wave's image [4 ci][16 co][48 B]; lane -> byte
+    // o = 1024 j + 16 lane = (ci, 768-byte row position) -> source offset ci * CoutP * 48 + position; the slot / channel-tile part
+    // of the address is the scalar offset sW (+ 4 CoutP 48 per slot; beyond the last slot: out of range, zeros)
+    unsigned wvl[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int o = j * 1024 + lane * 16;
+        const int ci = o / 768;
+        wvl[j] = (unsigned)(ci * g.CoutP * 48 + (o - ci * 768));
+    }
+    const int wstep = KQ * g.CoutP * 48;
+    const int sWend = 3 * g.CinP * g.CoutP * 48;
+    int sW = (co0 + cw * 16) * 48;
+    auto w_next = [&]() __attribute__((always_inline)) {
+        sW += wstep;
+        sW = sW < sWend ? sW : sWend;
+    };
+    f32x4* const Ww = Wb + wave * WWV;                   // this wave's part of ring position 0
+#define X_DMA(rp, j) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(Ww + (rp) * WSL + (j) * 64), 16, wvl[j], sW, 0, 0);
+#define X_FENCE0 __builtin_amdgcn_sched_barrier(0);
+#if (ABL & 256)
+#define X_WAITVM(n) asm volatile("s_waitcnt vmcnt(0)");
+#elif (ABL & 512)
+#define X_WAITVM(n) asm volatile("s_waitcnt vmcnt(0)"); __builtin_amdgcn_s_barrier();
+#else
+#define X_WAITVM(n) asm volatile("s_waitcnt vmcnt(" #n ")");
+#endif
+
+    f32x4 xvm[4], xve[2];
+    float xhl = 0.f, xsc = 1.f;
+    float xh[6];
+    int pS = 0;
+    xve[0] = xve[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto issue_rows = [&](int ci0, int r0, int r1) __attribute__((always_inline)) {
+        const int so = (ci0 + 2 * wave) * cs1 * 4;
+#pragma unroll
+        for (int r = 1; r < 5; ++r) {
+            if (r < r0 || r >= r1) continue;
+            xvm[r - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[r], so, 0));
+        }
+    };
+    auto issue_halo = [&](int ci0) __attribute__((always_inline)) {
+        const int so = (ci0 + 2 * wave) * cs1 * 4;
+        xhl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ehalo, so, 0));
+    };
+    auto issue_isc = [&](int ci0) __attribute__((always_inline)) {
+        if (HAS_ISC) {
+            const float s0 = a.in_scale[(long)b * a.Cin + ci0 + 2 * wave], s1 = a.in_scale[(long)b * a.Cin + ci0 + 2 * wave + 1];
+            xsc = s_ch ? s1 : s0;
+        }
+    };
+    auto issue_edge = [&](int ps, int ci0) __attribute__((always_inline)) {
+        const int so = (ci0 + 2 * wave) * cs1 * 4;
+        const unsigned edge = ps == 2 ? 0u : OOBH;
+        xve[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[0] | edge, so, 0));
+        xve[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[5] | edge, so, 0));
+    };
+    auto dpp_shr1 = [](float old, float src) __attribute__((always_inline)) {
+        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+        return old;
+    };
+    auto dpp_shl1 = [](float old, float src) __attribute__((always_inline)) {
+        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+        return old;
+    };
+    auto fsel = [](int ps, unsigned c0, unsigned c1, unsigned c2) __attribute__((always_inline)) {
+        return __builtin_bit_cast(float, ps == 0 ? c0 : (ps == 1 ? c1 : c2));
+    };
+    auto tt = [](const float (&E)[6], float (&U)[6]) {
+        const float e = E[4] - 4.f * E[2], o = E[3] - 4.f * E[1];
+        const float e2 = E[4] - E[2], o2 = E[3] - E[1];
+        U[0] = 4.f * E[0] + (E[4] - 5.f * E[2]);
+        U[1] = e + o;
+        U[2] = e - o;
+        U[3] = e2 + 2.f * o2;
+        U[4] = e2 - 2.f * o2;
+        U[5] = 4.f * E[1] + (E[5] - 5.f * E[3]);
+    };
+    // halo samples of the rows held in the staging registers -> xh[] (issued one MFMA group before the transform; the
+    // statement that consumes them waits).  Rows 0 / 5 are used by pass 2 only; their two bpermutes are issued in every pass
+    // (an LDS instruction does not cost matrix-pipe time, a branch here would cost hipcc's register shuffling)
+    auto halo_permute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(xh[r]) : "v"(hsrc), "v"(xhl), "n"(32 * r));
+    };
+    // (same arithmetic, in the same order, as conv_wino45_kernel::store_act: bit-identical products)
+    auto store_act = [&](f32x4* buf) __attribute__((always_inline)) {
+        const int ps = pS;
+        const f32x4 xv[6] = {xve[0], xvm[0], xvm[1], xvm[2], xvm[3], xve[1]};
+        const float k2 = fsel(ps, 0x40800000u, 0x3f800000u, 0x40a00000u);
+        const float k1 = fsel(ps, 0x40800000u, 0x40000000u, 0x40800000u);
+        const float k3 = fsel(ps, 0x3f800000u, 0x40000000u, 0x40a00000u);
+        const float x0 = fsel(ps, 0u, 0u, 0x40800000u), za = fsel(ps, 0x3f800000u, 0x3f800000u, 0u);
+        const float x5 = fsel(ps, 0u, 0u, 0x3f800000u), ye = za;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]), "+v"(xh[5]));
+        float Ea[6], Eb[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float d[6];
+#pragma unroll
+            for (int r = 1; r < 5; ++r)
+                d[r] = j == 0 ? dpp_shr1(xh[r], xv[r][3]) : (j == 5 ? dpp_shl1(xh[r], xv[r][0]) : xv[r][j - 1]);
+            const float e = d[4] - k2 * d[2];
+            const float o = k3 * d[3] - k1 * d[1];
+            Ea[j] = za * o + e;
+            Eb[j] = ye * e - o;
+        }
+        if (ps == 2) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d0 = j == 0 ? dpp_shr1(xh[0], xv[0][3]) : (j == 5 ? dpp_shl1(xh[0], xv[0][0]) : xv[0][j - 1]);
+                const float d5 = j == 0 ? dpp_shr1(xh[5], xv[5][3]) : (j == 5 ? dpp_shl1(xh[5], xv[5][0]) : xv[5][j - 1]);
+                Ea[j] = x0 * d0 + Ea[j];
+                Eb[j] = x5 * d5 + Eb[j];
+            }
+        }
+        if (HAS_ISC) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                Ea[j] *= xsc;
+                Eb[j] *= xsc;
+            }
+        }
+        float Ua[6], Ub[6];
+        tt(Ea, Ua);
+        tt(Eb, Ub);
+        buf[xlds] = f32x4{Ua[0], Ua[1], Ua[2], Ua[3]};
+        buf[xlds + 1] = f32x4{Ua[4], Ua[5], Ub[0], Ub[1]};
+        buf[xlds + 2] = f32x4{Ub[2], Ub[3], Ub[4], Ub[5]};
+    };
+    auto advance = [&](int& ps, int& ci0) __attribute__((always_inline)) {    // next super-slab, clamped at the last one
+        int nc = ci0 + KS, np = ps;
+        if (nc >= g.CinP) {
+            nc = 0;
+            ++np;
+        }
+        if (np <= 2) {
+            ps = np;
+            ci0 = nc;
+        }
+    };
+
+    // operand addresses (float4 units): A in the wave's ring part (slot i of a super-slab = ring position i), B in X
+    const int aoff = (lk * 16 + l15) * 3;
+    const int boff = (lk * NU + sg0 * 16 + l15) * 3;
+
+    // ---- prologue: super-slab 0 transformed into X[0], rows of super-slab 1 in flight, weight slots 0-2 in ring 0-2
+    int pA = 0, cA = 0;
+    issue_edge(pA, cA);
+    issue_rows(cA, 1, 5);
+    issue_halo(cA);
+    issue_isc(cA);
+    pS = pA;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        X_DMA(i, 0)
+        X_DMA(i, 1)
+        X_DMA(i, 2)
+        w_next();
+    }
+    X_FENCE0
+    halo_permute();
+    store_act(Xb);
+    X_FENCE0
+    advance(pA, cA);
+    issue_edge(pA, cA);
+    issue_rows(cA, 1, 5);
+    issue_halo(cA);
+    issue_isc(cA);
+    pS = pA;
+    X_FENCE0
+    asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)");        // the 9 weight DMAs landed (7 younger loads stay in flight)
+    __builtin_amdgcn_s_barrier();
+
+    X_FENCE0
+    f32x4 acc[2][12];                                     // (zeroed after the prologue's transform: 96 registers less while it runs)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 12; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 av[2], bv[2][2];
+#define X_MFMA(c, pg)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+        acc[0][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][0][i], acc[0][4 * (pg) + i], 0, 0, 0); \
+        if (two) acc[1][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][1][i], acc[1][4 * (pg) + i], 0, 0, 0); \
+    }
+#define X_READ(c, Xp, sl, pg)                                       \
+    av[c] = Ww[(sl) * WSL + aoff + (pg)];                           \
+    bv[c][0] = (Xp)[boff + (sl) * KQ * NU * 3 + (pg)];              \
+    if (two) bv[c][1] = (Xp)[boff + (sl) * KQ * NU * 3 + 16 * 3 + (pg)];
+#define X_FENCE __builtin_amdgcn_sched_barrier(0);
+    // group g: [DMA / loads] [reads of group g + 1 into the other set] [8 MFMAs of group g]
+#define X_GROUP(rp, j, cr, Xp, sl, pgr, cm, pgm) \
+    X_DMA(rp, j)                                 \
+    X_FENCE                                      \
+    X_READ(cr, Xp, sl, pgr)                      \
+    X_FENCE                                      \
+    X_MFMA(cm, pgm)                              \
+    X_FENCE
+    X_READ(0, Xb, 0, 0)
+    halo_permute();                                       // (super-slab 1's halo: waits for its load)
+    int cM = 0, pM = 0;
+    for (int S = 0; S < NS; ++S) {
+        const f32x4* Xs = Xb + (S & 1) * XSZ;
+        f32x4* Xw = Xb + ((S + 1) & 1) * XSZ;
+        // g0: transform of super-slab S + 1 (rows loaded during super-slab S - 1), then the loads of super-slab S + 2
+        X_DMA(3, 0)
+        X_FENCE
+        X_READ(1, Xs, 0, 1)
+        X_FENCE
+        store_act(Xw);
+        advance(pA, cA);
+        issue_isc(cA);
+        pS = pA;
+        X_FENCE
+        issue_edge(pA, cA);
+        issue_rows(cA, 1, 3);
+        X_FENCE
+        X_MFMA(0, 0)
+        X_FENCE
+        // g1
+        X_DMA(3, 1)
+        X_FENCE
+        issue_rows(cA, 3, 5);
+        X_FENCE
+        X_READ(0, Xs, 0, 2)
+        X_FENCE
+        X_MFMA(1, 1)
+        X_FENCE
+        // g2: first operands of slot 1
+        X_DMA(3, 2)
+        X_FENCE
+        issue_halo(cA);
+        w_next();
+        X_FENCE
+        X_WAITVM(13)
+        X_READ(1, Xs, 1, 0)
+        X_FENCE
+        X_MFMA(0, 2)
+        X_FENCE
+        X_GROUP(0, 0, 0, Xs, 1, 1, 1, 0)                  // g3
+        X_GROUP(0, 1, 1, Xs, 1, 2, 0, 1)                  // g4
+        X_DMA(0, 2)                                       // g5: first operands of slot 2
+        w_next();
+        X_FENCE
+        X_WAITVM(13)
+        X_READ(0, Xs, 2, 0)
+        X_FENCE
+        X_MFMA(1, 2)
+        X_FENCE
+        X_GROUP(1, 0, 1, Xs, 2, 1, 0, 0)                  // g6
+        X_GROUP(1, 1, 0, Xs, 2, 2, 1, 1)                  // g7
+        X_DMA(1, 2)                                       // g8: first operands of slot 3
+        w_next();
+        X_FENCE
+        X_WAITVM(6)                                       // (7 would do - the halo load follows D(3, 2) -; 6 does not depend on that order)
+        X_READ(1, Xs, 3, 0)
+        X_FENCE
+        X_MFMA(0, 2)
+        X_FENCE
+        X_GROUP(2, 0, 0, Xs, 3, 1, 1, 0)                  // g9
+        X_GROUP(2, 1, 1, Xs, 3, 2, 0, 1)                  // g10
+        // g11: X[(S + 1) & 1] is complete and nobody reads X[S & 1] any more (the operands of this group are in registers):
+        // barrier, first operands of the next super-slab + the halo permutes of super-slab S + 2 behind this group's MFMAs
+        X_DMA(2, 2)
+        w_next();
+        X_FENCE
+        X_WAITVM(6)
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        __builtin_amdgcn_s_barrier();
+        X_FENCE
+        X_READ(0, Xw, 0, 0)
+        halo_permute();
+        X_FENCE
+        X_MFMA(1, 2)
+        X_FENCE
+        cM += KS;
+        if (cM >= g.CinP) {
+            // pass boundary (twice per tile): the finished phases are carried IN PLACE.  Written as inline assembly with tied
+            // operands: as C++ expressions hipcc computed the 96 results into 96 fresh registers and copied them back on the
+            // loop's back edge - 255 registers for a kernel whose loop needs 175.  The rounding is that of the expressions of
+            // conv_wino45_kernel::carry as hipcc contracts them (0.25 m is exact, so fma(0.75, m1, 0.25 m2) is the correctly
+            // rounded 0.75 m1 + 0.25 m2; 2 (m3 - m4) likewise): bit-identical.  s_nop: the MFMAs of the last group may still be
+            // writing the accumulators, and the hazard recogniser does not look inside inline assembly.
+            cM = 0;
+            asm volatile("s_nop 15\n\ts_nop 15");
+            if (pM == 0) {
+                float c75 = 0.75f;
+                asm volatile("" : "+s"(c75));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 6; ++p)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t0;
+                            // m1' = fma(0.75, m1, 0.25 m2)  (0.25 m2 exact);  m2' = fma(0.25, m1, round(0.75 m2)): the
+                            // contraction hipcc chose for the C++ expressions of the other two kernels - kept, bit for bit
+                            asm volatile("v_mul_f32 %2, 0x3e800000, %1\n\tv_mul_f32 %1, 0x3f400000, %1\n\t"
+                                         "v_fmac_f32 %1, 0x3e800000, %0\n\tv_fma_f32 %0, %3, %0, %2"
+                                         : "+v"(acc[i][p][e]), "+v"(acc[i][6 + p][e]), "=&v"(t0) : "s"(c75));
+                        }
+            } else if (pM == 1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 6; ++p)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t0;
+                            asm volatile("v_sub_f32 %2, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_mul_f32 %1, 2.0, %2"
+                                         : "+v"(acc[i][p][e]), "+v"(acc[i][6 + p][e]), "=&v"(t0));
+                        }
+            }
+            asm volatile("s_nop 4");
+            ++pM;
+        }
+    }
+#undef X_MFMA
+#undef X_READ
+#undef X_GROUP
+#undef X_FENCE
+#undef X_DMA
+#undef X_FENCE0
+#undef X_WAITVM
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");          // (the tail's clamped loads / out-of-range DMAs: nothing may land after the exit)
+
+    // ---- output (as conv_wino45w_kernel)
+    const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i == 1 && !two) break;
+        const int sg = i == 0 ? sg0 : 1;
+        const int t = t0 + 64 * (sg & tbm) + 4 * l15;
+        const int fa = pair_row(sg >> g.tsh);
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            const int f = fa + row * a.dil;
+            const bool pv = f < a.F && t < a.T;
+            const long sp = pv ? (long)f * a.T + t : 0;
+            float os[4];
+            f32x4 rr[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = co0 + cw * 16 + 4 * lk + kk;           // < Cout: Cout % BN == 0
+                os[kk] = has_os ? a.oscale[b * a.Cout + co] : 1.f;
+                rr[kk] = has_res ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)co * a.res_cs + sp)
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = co0 + cw * 16 + 4 * lk + kk;
+                const float m0 = acc[i][6 * row + 0][kk], m1 = acc[i][6 * row + 1][kk], m2 = acc[i][6 * row + 2][kk];
+                const float m3 = acc[i][6 * row + 3][kk], m4 = acc[i][6 * row + 4][kk], m5 = acc[i][6 * row + 5][kk];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                f32x4 y = {m0 + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + m5};
+                const float sc = a.alpha * os[kk];
+                y = y * sc + a.rbeta * rr[kk];
+                if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
+            }
+        }
+    }
+#endif
+}
+
 // dst [3 passes][CinP][CoutP][12]: pass ps holds frequency phases (1,2), (3,4), (0,5); entry 6*fpl + tp
 __global__ void pack_wino45_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int tf, int CinP,
                                    int CoutP, long total) {
@@ -1022,6 +1475,25 @@ extern "C" int babe_conv2d_wino45(const babe_conv_args* ap, const float* w_wino4
         g.groups = cdiv(a.dil * g.npairs, 2 >> g.tsh);
         const int bnw = a.Cout % 128 == 0 ? 128 : 96;
         dim3 gridw(g.tiles_t * g.groups, a.Cout / bnw, a.B);
+        static const char* ovx = getenv("BABE_CONV_WINO45X");
+        if (!(ovx && ovx[0] == '0')) {                  // second-generation pipeline (wave-private weights, two operand sets)
+            const size_t ldsx = (size_t)(2 * 16 * 32 * 3 + 4 * 8 * 4 * 16 * 3) * 16;   // 144 KB
+            static std::atomic<unsigned long long> attr_x{0};
+            if (babe_lds_optin(attr_x, {reinterpret_cast<const void*>(&conv_wino45x_kernel<true, 128>),
+                                        reinterpret_cast<const void*>(&conv_wino45x_kernel<false, 128>),
+                                        reinterpret_cast<const void*>(&conv_wino45x_kernel<true, 96>),
+                                        reinterpret_cast<const void*>(&conv_wino45x_kernel<false, 96>)}, (int)ldsx) == hipSuccess) {
+                if (bnw == 128) {
+                    if (a.in_scale) hipLaunchKernelGGL((conv_wino45x_kernel<true, 128>), gridw, dim3(512), ldsx, s, a, g, w_wino45);
+                    else hipLaunchKernelGGL((conv_wino45x_kernel<false, 128>), gridw, dim3(512), ldsx, s, a, g, w_wino45);
+                } else {
+                    if (a.in_scale) hipLaunchKernelGGL((conv_wino45x_kernel<true, 96>), gridw, dim3(512), ldsx, s, a, g, w_wino45);
+                    else hipLaunchKernelGGL((conv_wino45x_kernel<false, 96>), gridw, dim3(512), ldsx, s, a, g, w_wino45);
+                }
+            }
+            BABE_LAUNCH_CHECK();
+            return BABE_OK;
+        }
         const size_t ldsw = (size_t)(2 * 16 * 32 * 3 + 2 * 8 * bnw * 3) * 16;       // 144 KB (120 KB for 96-channel tiles)
         static std::atomic<unsigned long long> attr_w{0};
         if (babe_lds_optin(attr_w, {reinterpret_cast<const void*>(&conv_wino45w_kernel<true, 128>),

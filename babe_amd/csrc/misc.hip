@@ -62,6 +62,7 @@ extern "C" int babe_prof_nslots(void) { return BABE_NSLOTS; }
 extern "C" const char* babe_prof_slot_name(int slot) { return (slot >= 0 && slot < BABE_NSLOTS) ? kSlotNames[slot] : ""; }
 /* on: start tallying (a fresh tally unless one is pending); off: stop, what was recorded stays until babe_prof_read() */
 extern "C" int babe_prof_enable(int on) {
+    if (on < 0) return g_prof.on ? 1 : 0;           // query (the host's graph capture asks the library, not a shadow flag)
     g_prof.on = on != 0;
     g_prof.open = false;
     return BABE_OK;

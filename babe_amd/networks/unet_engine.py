@@ -16,6 +16,7 @@ import math
 import torch
 
 from .. import ops
+from .._lib import bump_alloc_generation
 
 RS2 = 1.0 / math.sqrt(2.0)
 
@@ -111,6 +112,7 @@ class UnetEngine:
         if t is None or t.numel() < numel:
             t = torch.empty(numel, device=self.dev, dtype=torch.float32)
             self._scratch[name] = t
+            bump_alloc_generation()          # captured HIP graphs hold the old tensor's address
         return t[:numel]
 
     def scratch_i16(self, name, numel):
@@ -118,6 +120,7 @@ class UnetEngine:
         if t is None or t.numel() < numel:
             t = torch.empty(numel, device=self.dev, dtype=torch.int16)
             self._scratch[name] = t
+            bump_alloc_generation()
         return t[:numel]
 
     def embed(self, cnoise):

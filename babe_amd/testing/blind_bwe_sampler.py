@@ -359,9 +359,15 @@ class BlindSampler:
         if getattr(self, "_lane_streams", None) is None or len(self._lane_streams) < nl:
             self._lane_streams = [torch.cuda.Stream(device=dev) for _ in range(nl)]
         noises = [self._randn((B, L), dev).contiguous() for _ in range(T)]          # reference order: one draw per step
-        from .._lib import prof_enabled
+        from .._lib import prof_enabled, alloc_generation
         if not hasattr(self, "_graphs"):
             self._graphs = {}
+        # graphs bake raw device pointers (engine scratch, packed weights, STFT / CQT tables) that they do not keep alive:
+        # whenever one of those has been (re)allocated since a capture - a later eager call with a larger batch or length, a
+        # second configuration's first call, re-packed weights - every captured graph is dropped (never replayed)
+        if getattr(self, "_graphs_gen", None) != alloc_generation():
+            self._graphs = {k_: {} for k_, v_ in self._graphs.items() if not v_.get("failed")}
+            self._graphs_gen = alloc_generation()
         key = self._graph_key(x, blind, snoise, t, gamma, filter_params, nl)
         gs = self._graphs.get(key) if (self.GRAPHS and not prof_enabled()) else None
         if gs is not None and gs.get("failed"):
@@ -431,6 +437,8 @@ class BlindSampler:
             lanes.append(ln)
             graphs.append(gl)
         gs.update(static=st, lanes=lanes, graphs=graphs)
+        from .._lib import alloc_generation
+        self._graphs_gen = alloc_generation()               # (allocations made DURING the capture belong to the graphs' pools)
 
     def _replay_lanes(self, gs, x, y, specY, filter_params, noises, main):
         st, lanes, graphs = gs["static"], gs["lanes"], gs["graphs"]

@@ -112,7 +112,7 @@ int babe_conv2d_fewco_supported(const babe_conv_args* a);
  * kernel a conv call really dispatched to.  Diagnostics only; single host thread. */
 int babe_prof_nslots(void);
 const char* babe_prof_slot_name(int slot);
-int babe_prof_enable(int on);
+int babe_prof_enable(int on);          /* on < 0: query, returns 1 / 0 */
 int babe_prof_conv_slot(int slot);      /* >= 0: tally conv launches in that slot (the CQT's dense DFT stages); -1: off */
 int babe_prof_read(double* ms, double* bytes, double* flops, double* exec_flops, long* launches);
 int babe_prof_dispatch_counts(long* counts, int reset);
