@@ -29,6 +29,7 @@
 #include "../../include/babe_hip.h"
 #include "prof.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -1154,136 +1155,136 @@ __global__ __launch_bounds__(512, 1) void conv_wino45x_kernel(babe_conv_args a, 
     bv[c][0] = (Xp)[boff + (sl) * KQ * NU * 3 + (pg)];              \
     if (two) bv[c][1] = (Xp)[boff + (sl) * KQ * NU * 3 + 16 * 3 + (pg)];
 #define X_FENCE __builtin_amdgcn_sched_barrier(0);
-    // group g: [DMA / loads] [reads of group g + 1 into the other set] [8 MFMAs of group g]
-#define X_GROUP(rp, j, cr, Xp, sl, pgr, cm, pgm) \
-    X_DMA(rp, j)                                 \
-    X_FENCE                                      \
-    X_READ(cr, Xp, sl, pgr)                      \
-    X_FENCE                                      \
-    X_MFMA(cm, pgm)                              \
+    // group g: [weight DMA chunk] [staging loads] [wait for a new slot's weights] [reads of group g + 1 into the other operand
+    // set] [transform] [8 MFMAs of group g].  STAGGER: the two waves of a SIMD (w, w + 4) do their staging work - transform
+    // (~90 vector instructions and two LDS round trips during which the wave issues no MFMA) and row loads - half a super-slab
+    // apart: waves 0-3 in groups 0-2 (EARLY), waves 4-7 in groups 6-8 (LATE), so that one partner multiplies while the other
+    // transforms - OPTIONAL, see below.  Two copies of the loop (generic lambda): every count is a compile-time constant.
+    //   vmcnt, EARLY (see the header): 13, 13, 6, 6 at g2, g5, g8, g11;
+    //   LATE issues  g0-g5: D | g6: D E E R R | g7: D R R | g8: D H | g9-g11: D  ->  6, 6, 13, 13.
+#define X_G(g, rp, j, cr, sl, pgr, cm, pgm)                                                                     \
+    X_DMA(rp, j)                                                                                                \
+    X_FENCE                                                                                                     \
+    if constexpr ((g) == SA + 1) {                                                                              \
+        issue_rows(cA, 3, 5);                                                                                   \
+        X_FENCE                                                                                                 \
+    }                                                                                                           \
+    if constexpr ((g) == SA + 2) {                                                                              \
+        issue_halo(cA);                                                                                         \
+        X_FENCE                                                                                                 \
+    }                                                                                                           \
+    if constexpr ((j) == 2) {                                                                                   \
+        w_next();                                                                                               \
+        if constexpr (((g) < 6) != LATE) { X_WAITVM(13) } else { X_WAITVM(6) }                                  \
+    }                                                                                                           \
+    X_READ(cr, Xs, sl, pgr)                                                                                     \
+    X_FENCE                                                                                                     \
+    if constexpr ((g) == SA) {                                                                                  \
+        /* transform of super-slab S + 1 (rows loaded one super-slab ago), then the loads of super-slab S + 2 */ \
+        store_act(Xw);                                                                                          \
+        advance(pA, cA);                                                                                        \
+        issue_isc(cA);                                                                                          \
+        pS = pA;                                                                                                \
+        X_FENCE                                                                                                 \
+        issue_edge(pA, cA);                                                                                     \
+        issue_rows(cA, 1, 3);                                                                                   \
+        X_FENCE                                                                                                 \
+    }                                                                                                           \
+    if constexpr (LATE && (g) == 5) {                                                                           \
+        halo_permute();                                                                                         \
+        X_FENCE                                                                                                 \
+    }                                                                                                           \
+    X_MFMA(cm, pgm)                                                                                             \
     X_FENCE
-    X_READ(0, Xb, 0, 0)
-    halo_permute();                                       // (super-slab 1's halo: waits for its load)
-    int cM = 0, pM = 0;
-    for (int S = 0; S < NS; ++S) {
-        const f32x4* Xs = Xb + (S & 1) * XSZ;
-        f32x4* Xw = Xb + ((S + 1) & 1) * XSZ;
-        // g0: transform of super-slab S + 1 (rows loaded during super-slab S - 1), then the loads of super-slab S + 2
-        X_DMA(3, 0)
-        X_FENCE
-        X_READ(1, Xs, 0, 1)
-        X_FENCE
-        store_act(Xw);
-        advance(pA, cA);
-        issue_isc(cA);
-        pS = pA;
-        X_FENCE
-        issue_edge(pA, cA);
-        issue_rows(cA, 1, 3);
-        X_FENCE
-        X_MFMA(0, 0)
-        X_FENCE
-        // g1
-        X_DMA(3, 1)
-        X_FENCE
-        issue_rows(cA, 3, 5);
-        X_FENCE
-        X_READ(0, Xs, 0, 2)
-        X_FENCE
-        X_MFMA(1, 1)
-        X_FENCE
-        // g2: first operands of slot 1
-        X_DMA(3, 2)
-        X_FENCE
-        issue_halo(cA);
-        w_next();
-        X_FENCE
-        X_WAITVM(13)
-        X_READ(1, Xs, 1, 0)
-        X_FENCE
-        X_MFMA(0, 2)
-        X_FENCE
-        X_GROUP(0, 0, 0, Xs, 1, 1, 1, 0)                  // g3
-        X_GROUP(0, 1, 1, Xs, 1, 2, 0, 1)                  // g4
-        X_DMA(0, 2)                                       // g5: first operands of slot 2
-        w_next();
-        X_FENCE
-        X_WAITVM(13)
-        X_READ(0, Xs, 2, 0)
-        X_FENCE
-        X_MFMA(1, 2)
-        X_FENCE
-        X_GROUP(1, 0, 1, Xs, 2, 1, 0, 0)                  // g6
-        X_GROUP(1, 1, 0, Xs, 2, 2, 1, 1)                  // g7
-        X_DMA(1, 2)                                       // g8: first operands of slot 3
-        w_next();
-        X_FENCE
-        X_WAITVM(6)                                       // (7 would do - the halo load follows D(3, 2) -; 6 does not depend on that order)
-        X_READ(1, Xs, 3, 0)
-        X_FENCE
-        X_MFMA(0, 2)
-        X_FENCE
-        X_GROUP(2, 0, 0, Xs, 3, 1, 1, 0)                  // g9
-        X_GROUP(2, 1, 1, Xs, 3, 2, 0, 1)                  // g10
-        // g11: X[(S + 1) & 1] is complete and nobody reads X[S & 1] any more (the operands of this group are in registers):
-        // barrier, first operands of the next super-slab + the halo permutes of super-slab S + 2 behind this group's MFMAs
-        X_DMA(2, 2)
-        w_next();
-        X_FENCE
-        X_WAITVM(6)
-        asm volatile("s_waitcnt lgkmcnt(0)");
-        __builtin_amdgcn_s_barrier();
-        X_FENCE
-        X_READ(0, Xw, 0, 0)
-        halo_permute();
-        X_FENCE
-        X_MFMA(1, 2)
-        X_FENCE
-        cM += KS;
-        if (cM >= g.CinP) {
-            // pass boundary (twice per tile): the finished phases are carried IN PLACE.  Written as inline assembly with tied
-            // operands: as C++ expressions hipcc computed the 96 results into 96 fresh registers and copied them back on the
-            // loop's back edge - 255 registers for a kernel whose loop needs 175.  The rounding is that of the expressions of
-            // conv_wino45_kernel::carry as hipcc contracts them (0.25 m is exact, so fma(0.75, m1, 0.25 m2) is the correctly
-            // rounded 0.75 m1 + 0.25 m2; 2 (m3 - m4) likewise): bit-identical.  s_nop: the MFMAs of the last group may still be
-            // writing the accumulators, and the hazard recogniser does not look inside inline assembly.
-            cM = 0;
-            asm volatile("s_nop 15\n\ts_nop 15");
-            if (pM == 0) {
-                float c75 = 0.75f;
-                asm volatile("" : "+s"(c75));
+    auto run = [&](auto late_c) __attribute__((always_inline)) {
+        constexpr bool LATE = decltype(late_c)::value;
+        constexpr int SA = LATE ? 6 : 0;
+        X_READ(0, Xb, 0, 0)
+        if constexpr (!LATE) halo_permute();              // (super-slab 1's halo: waits for its load)
+        int cM = 0, pM = 0;
+        for (int S = 0; S < NS; ++S) {
+            const f32x4* Xs = Xb + (S & 1) * XSZ;
+            f32x4* Xw = Xb + ((S + 1) & 1) * XSZ;
+            X_G(0, 3, 0, 1, 0, 1, 0, 0)
+            X_G(1, 3, 1, 0, 0, 2, 1, 1)
+            X_G(2, 3, 2, 1, 1, 0, 0, 2)                   // first operands of slot 1
+            X_G(3, 0, 0, 0, 1, 1, 1, 0)
+            X_G(4, 0, 1, 1, 1, 2, 0, 1)
+            X_G(5, 0, 2, 0, 2, 0, 1, 2)                   // first operands of slot 2
+            X_G(6, 1, 0, 1, 2, 1, 0, 0)
+            X_G(7, 1, 1, 0, 2, 2, 1, 1)
+            X_G(8, 1, 2, 1, 3, 0, 0, 2)                   // first operands of slot 3
+            X_G(9, 2, 0, 0, 3, 1, 1, 0)
+            X_G(10, 2, 1, 1, 3, 2, 0, 1)
+            // g11: X[(S + 1) & 1] is complete and nobody reads X[S & 1] any more (the operands of this group are in
+            // registers): barrier, then the first operand reads of the next super-slab (+ the EARLY waves' halo permutes of
+            // super-slab S + 2) run behind this group's MFMAs
+            X_DMA(2, 2)
+            w_next();
+            X_FENCE
+            if constexpr (LATE) { X_WAITVM(13) } else { X_WAITVM(6) }
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            __builtin_amdgcn_s_barrier();
+            X_FENCE
+            X_READ(0, Xw, 0, 0)
+            if constexpr (!LATE) halo_permute();
+            X_FENCE
+            X_MFMA(1, 2)
+            X_FENCE
+            cM += KS;
+            if (cM >= g.CinP) {
+                // pass boundary (twice per tile): the finished phases are carried IN PLACE.  Written as inline assembly with
+                // tied operands: as C++ expressions hipcc computed the 96 results into 96 fresh registers and copied them back
+                // on the loop's back edge - 255 registers for a kernel whose loop needs 175.  The rounding is that of the
+                // expressions of conv_wino45_kernel::carry as hipcc contracts them: bit-identical.  s_nop: the MFMAs of the last
+                // group may still be writing the accumulators, and the hazard recogniser does not look inside inline assembly.
+                cM = 0;
+                asm volatile("s_nop 15\n\ts_nop 15");
+                if (pM == 0) {
+                    float c75 = 0.75f;
+                    asm volatile("" : "+s"(c75));
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int p = 0; p < 6; ++p)
+                        for (int p = 0; p < 6; ++p)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float t0;
-                            // m1' = fma(0.75, m1, 0.25 m2)  (0.25 m2 exact);  m2' = fma(0.25, m1, round(0.75 m2)): the
-                            // contraction hipcc chose for the C++ expressions of the other two kernels - kept, bit for bit
-                            asm volatile("v_mul_f32 %2, 0x3e800000, %1\n\tv_mul_f32 %1, 0x3f400000, %1\n\t"
-                                         "v_fmac_f32 %1, 0x3e800000, %0\n\tv_fma_f32 %0, %3, %0, %2"
-                                         : "+v"(acc[i][p][e]), "+v"(acc[i][6 + p][e]), "=&v"(t0) : "s"(c75));
-                        }
-            } else if (pM == 1) {
+                            for (int e = 0; e < 4; ++e) {
+                                float t0;
+                                // m1' = fma(0.75, m1, 0.25 m2)  (0.25 m2 exact);  m2' = fma(0.25, m1, round(0.75 m2)): the
+                                // contraction hipcc chose for the C++ expressions of the other two kernels - kept, bit for bit
+                                asm volatile("v_mul_f32 %2, 0x3e800000, %1\n\tv_mul_f32 %1, 0x3f400000, %1\n\t"
+                                             "v_fmac_f32 %1, 0x3e800000, %0\n\tv_fma_f32 %0, %3, %0, %2"
+                                             : "+v"(acc[i][p][e]), "+v"(acc[i][6 + p][e]), "=&v"(t0) : "s"(c75));
+                            }
+                } else if (pM == 1) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int p = 0; p < 6; ++p)
+                        for (int p = 0; p < 6; ++p)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float t0;
-                            asm volatile("v_sub_f32 %2, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_mul_f32 %1, 2.0, %2"
-                                         : "+v"(acc[i][p][e]), "+v"(acc[i][6 + p][e]), "=&v"(t0));
-                        }
+                            for (int e = 0; e < 4; ++e) {
+                                float t0;
+                                asm volatile("v_sub_f32 %2, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_mul_f32 %1, 2.0, %2"
+                                             : "+v"(acc[i][p][e]), "+v"(acc[i][6 + p][e]), "=&v"(t0));
+                            }
+                }
+                asm volatile("s_nop 4");
+                ++pM;
             }
-            asm volatile("s_nop 4");
-            ++pM;
         }
-    }
+    };
+    // Measured (round 4, same box, six layer shapes): staggered 2.42 ms, not staggered 2.40 ms - no gain, as round 3 found for
+    // the first-generation kernel (the vector work costs matrix-pipe time whichever wave does it, and the LDS round trips it
+    // exposes are short).  Default: every wave EARLY (one copy of the loop); -DABL=1024 builds the staggered form.
+#if (ABL & 1024)
+    if (wave >= 4) run(std::true_type{});
+    else run(std::false_type{});
+#else
+    run(std::false_type{});
+#endif
+#undef X_G
 #undef X_MFMA
 #undef X_READ
-#undef X_GROUP
 #undef X_FENCE
 #undef X_DMA
 #undef X_FENCE0

@@ -157,7 +157,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
     MAX_LANES = int(os.environ.get("BABE_UNET_STREAMS", "2"))
 
     def _get_lanes(self, B):
-        n = min(B, self.MAX_LANES) if self.concurrent_lanes_ok else 1      # (BABE_BF16_LANES=0: bf16 on one stream)
+        n = min(B, self.MAX_LANES) if self.concurrent_lanes_ok else 1      # (bf16: one stream unless BABE_BF16_LANES=1)
         if n <= 1:
             return None
         if getattr(self, "_lanes", None) is None or len(self._lanes) != n:
@@ -196,13 +196,15 @@ class Unet_CQT_oct_with_attention(nn.Module):
 
     # ---------------------------------------------------------------- raw (no autograd) interface
     supports_lanes = True
-    # (Round 3: with precision='bf16' two evaluation chains on two streams used to corrupt about one sampler run in four -
-    # kernels containing packed-fp32 instructions gave wrong sums beside the bf16 conv.  The library is built without any
-    # packed-fp32 instruction now, babe_amd/build.py, and the two-lane bf16 soak is clean; DESIGN.md 8.  BABE_BF16_LANES=0
-    # puts bf16 networks back on one stream.)
+    # precision='bf16': ONE stream by default.  Round 3 found that kernels containing packed-fp32 instructions return wrong sums
+    # when they run beside conv_bf16p (v_mfma_f32_32x32x16_bf16) on another stream.  This library is built without any packed-fp32
+    # instruction (babe_amd/build.py; tests/test_no_packed_fp32.py) and its two-lane soak is clean, but the root cause is not
+    # identified and kernels this library does not build (ATen copies / RNG, RCCL, a caller's own kernels) still
+    # contain such instructions and may run on other streams - a recurrence would be silent numerical corruption.  Two bf16
+    # lanes are therefore opt-in: BABE_BF16_LANES=1 (3.18 -> 3.68 audio-sec/s on the benchmark, round 3).  fp32 is unaffected.
     @property
     def concurrent_lanes_ok(self):
-        return self.precision != "bf16" or os.environ.get("BABE_BF16_LANES", "1") != "0"
+        return self.precision != "bf16" or os.environ.get("BABE_BF16_LANES", "0") == "1"
 
     def lane_engine(self, lane):
         """Engine state number `lane` (saved activations + scratch of its own over the shared packed weights): a caller that
