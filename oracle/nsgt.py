@@ -188,6 +188,9 @@ class CQT_nsgt:
             vals = torch.gather(fc, -1, o["pos"].expand(fc.shape[:-1] + o["pos"].shape[-1:])) * o["dwin"]
             flat_idx = o["idx"].reshape(-1)
             P = P.index_add(-1, flat_idx, vals.reshape(B, 1, -1))
+        # (the builder's own choice: the conjugate-mirrored bands are ADDED before a full inverse FFT; the library is believed
+        # to irfft the positive half only - SURVEY App. B "pitfall".  FIRST SUSPECT if tests/golden/cqt_lib.npz
+        # (tests/golden/make_cqt_golden.py, written only where cqt_nsgt_pytorch is importable) ever disagrees.)
         Pm = torch.conj(torch.roll(torch.flip(P, dims=(-1,)), 1, dims=-1))   # P[-n]
         x = torch.fft.ifft(P + Pm, dim=-1).real
         return x.to(self.dtype)

@@ -963,8 +963,81 @@ def g20(mu=(100.0, 1.0), probe=False):
                   float((x2 - xres).norm() / xres.norm()), "and the filter by", (fp2 - fp).abs().max().item())
     save("sampler_full_46046.npz", **out)
 
+# ---------------------------------------------------------------- G21: formal_test_bwe, non-AR segmentation + Hann OLA
+def g21():
+    """testing/blind_bwe_tester.py:320-578 BlindTester.formal_test_bwe(typefilter='fc_A', blind=True) with
+    formal_test.use_AR = False, driven through the reference's OWN method (glob / file read / wav writer / resampler / wandb
+    stubbed, the filter pickle goes to a temporary directory): the file is low-passed with the test filter (:386-388), cut into
+    segments of audio_len samples every segL - 200 - OLA samples (:421-469), each restored by predict_blind_bwe ON ITS OWN
+    (B = 1, sequential noise draws), windowed with the halves of a 2*OLA Hann window and overlap-added (:456-521), the last,
+    zero-padded segment added without a tail window (:521-566).  Reduced width, T = 3, 22.05 kHz, a 212000-sample file:
+    2.3 segments (2 full ones + a zero-padded third).  Pins babe_amd/testing/long_file.py::plan_segments / assemble."""
+    import tempfile
+    import types
+    for name in ("wandb", "omegaconf", "soundfile"):
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    tester = importlib.import_module("testing.blind_bwe_tester")
+    args = small_args(T=3)
+    args.tester.posterior_sampling.start_sigma = 0.05
+    args.tester.blind_bwe.optimization.mu = [100, 1]
+    fs, L = args.exp.sample_rate, 212000
+    tmp = tempfile.mkdtemp()
+    args.tester.formal_test = ref_shim.to_attr(dict(path="/nonexistent", folder=tmp, use_AR=False, OLA=256))
+    args.tester.complete_recording = ref_shim.to_attr(dict(overlap=0.25))
+    args.tester.blind_bwe.test_filter = ref_shim.to_attr(dict(fc=[2500.0], A=[-35.0]))
+    net, sd = build_ref_net(args)
+    g = torch.Generator().manual_seed(2121)
+    t_ax = torch.arange(L) / fs
+    clean = sum(0.05 / (k + 1) * torch.sin(2 * np.pi * 220.0 * (k + 1) * t_ax) * torch.exp(-(t_ax % 1.5) * (1 + k)) for k in range(12))
+    clean = clean + 0.1 * torch.randn(L, generator=g)
+    with quiet():
+        smp = samp_mod.BlindSampler(ResidualNetRef(net, 0.3, args.tester.diff_params.sigma_data), edm_mod.EDM(args), args)
+    written, calls = {}, []
+    blind_orig = smp.predict_blind_bwe
+
+    def blind_rec(y, rid=False):
+        r = blind_orig(y, rid=rid)
+        calls.append((y.detach().clone(), r[0].detach().clone(), r[1].detach().clone()))
+        return r
+
+    smp.predict_blind_bwe = blind_rec
+    fake = types.SimpleNamespace(args=args, device=torch.device("cpu"), sampler=smp, do_formal_test_bwe=True, test_set=[0])
+    fake.apply_lowpass_fcA = lambda seg, params: tester.BlindTester.apply_lowpass_fcA(fake, seg, params)
+    tester.glob = lambda pattern: ["/nonexistent/in.wav"]
+    tester.sf.read = lambda fn: (clean.double().numpy(), fs)
+    tester.wandb.Table = lambda columns=None: None
+    tester.utils_logging.write_audio_file = lambda x, sr, name, path=None: written.__setitem__(name, x.detach().clone())
+
+    def fake_resample(x, a, b):
+        assert a == b, "resample needed"
+        written["degraded"] = x.detach().clone()
+        return x
+
+    tester.torchaudio.functional = types.SimpleNamespace(resample=fake_resample)
+    gn = torch.Generator().manual_seed(2100)
+    orig = torch.randn
+    torch.randn = lambda *shape, **k: orig(*shape, generator=gn)
+    try:
+        with quiet(), contextlib.redirect_stderr(io.StringIO()):
+            tester.BlindTester.formal_test_bwe(fake, typefilter="fc_A", blind=True)
+    finally:
+        torch.randn = orig
+    assert len(calls) == 3, len(calls)
+    import pickle
+    with open(os.path.join(tmp, "in.filter_data.pkl"), "rb") as fh:
+        starts = np.array([int(span[0]) for span, _ in pickle.load(fh)])           # the reference's own record of its segment starts
+    save("formal_test_bwe.npz", final=written["in.wav"], degraded=written["degraded"], seg_starts=starts,
+         seg_in_sub16=torch.stack([c[0][0, ::16] for c in calls]), seg_pred=torch.stack([c[1][0] for c in calls]),
+         seg_filters=torch.stack([c[2].reshape(2, -1) for c in calls]),
+         seed=2121, noise_seed=2100, res_a=0.3, start_sigma=0.05, mu=np.array([100.0, 1.0]), L=L, OLA=256,
+         test_fc=2500.0, test_A=-35.0)
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
     for w in which:
         globals()[w]()

@@ -111,6 +111,42 @@ def test_complete_recording_flow_vs_reference_driver(use_denoiser):
     print(f"complete recording ({key}): RMS err {e_rms:.2e} (signal RMS {float(ref.std()):.3f}), rel {e_rel:.2e}")
     assert out.shape == ref.shape and e_rel < 3e-3
 
+def test_formal_test_bwe_non_ar_flow_vs_reference_driver():
+    """SURVEY 8f row 1, non-AR path: restore_file (segments of audio_len every segL - 200 - OLA samples, blind restoration of
+    each, Hann cross-fade) against the reference's OWN BlindTester.formal_test_bwe(typefilter='fc_A', blind=True) run with its
+    file I/O stubbed (tests/golden/make_golden.py::g21; /root/reference/testing/blind_bwe_tester.py:320-578).  The reference
+    restores its segments one at a time, drawing noise as it goes: batch_size = 1 with the same generator reproduces its draw
+    order; a second run with all three segments in ONE per-clip batch (what the benchmark and the multi-GPU sharding do) draws
+    different noise, so it is checked for structure only (finite, same loudness)."""
+    from babe_amd.config import default_args
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.networks.cqtdiff_plus import Unet_CQT_oct_with_attention
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    from babe_amd.testing.long_file import restore_file
+    s = np.load(os.path.join(G, "formal_test_bwe.npz"))
+    u = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(G, "unet_small.npz")).items()}
+    sd = {k[3:]: v for k, v in u.items() if k.startswith("sd.")}
+    fs, segL, L = 22050, 92092, int(s["L"])
+    args = default_args(sample_rate=fs, audio_len=segL, Ns=[8, 8, 8, 8, 16, 16, 16], T=3, start_sigma=float(s["start_sigma"]))
+    args.tester.blind_bwe.optimization.mu = [float(v) for v in s["mu"]]
+    net = Unet_CQT_oct_with_attention(args, "cuda")
+    net.load_state_dict(sd, strict=True)
+    smp = BlindSampler(ResidualNet(net, float(s["res_a"]), 0.063), EDM(args), args, batch_semantics="per_clip")
+    gn = torch.Generator().manual_seed(int(s["noise_seed"]))
+    smp._randn = lambda shape, device: torch.randn(*shape, generator=gn).to(device)
+    y = torch.from_numpy(s["degraded"])[0].cuda()
+    out, filters = restore_file(smp, y, batch_size=1, blind=True)
+    ref = torch.from_numpy(s["final"])[0]
+    e_rms, e_rel = rms_err(out, ref), rel(out, ref)
+    print(f"formal_test_bwe (non-AR, blind, 3 segments): RMS err {e_rms:.2e} (signal RMS {float(ref.std()):.3f}), rel {e_rel:.2e}")
+    assert out.shape == ref.shape and e_rms < 1e-3 and e_rel < 3e-3
+    assert [span[0] for span, _ in filters] == [int(v) for v in s["seg_starts"]]
+    fr = torch.from_numpy(s["seg_filters"])
+    for (_, f), r in zip(filters, fr):
+        assert torch.allclose(f.cpu()[0], r[0], rtol=1e-2) and torch.allclose(f.cpu()[1], r[1], atol=1.0), (f, r)
+    out_b, _ = restore_file(smp, y, batch_size=8, blind=True)
+    assert out_b.shape == ref.shape and bool(torch.isfinite(out_b).all()) and 0.5 < float(out_b.std()) / float(ref.std()) < 2.0
+
 
 @pytest.mark.parametrize("layout", ["trainer_ema", "ema_weights_all", "ema_weights_trainable"])
 def test_reference_format_checkpoint_restores_into_hip_net(layout, tmp_path):

@@ -112,6 +112,21 @@ def test_long_file_segmentation_and_crossfade(L):
     out = assemble(segs, plan, L, segL)
     assert torch.allclose(out, y, atol=1e-6)
 
+def test_long_file_plan_and_assemble_vs_reference_formal_test_bwe():
+    """plan_segments / assemble against the reference's OWN driver, BlindTester.formal_test_bwe (non-AR, blind;
+    /root/reference/testing/blind_bwe_tester.py:421-566), run with its file I/O stubbed (tests/golden/make_golden.py::g21) on a
+    2.3-segment file: the segment starts it recorded in its filter pickle, and its output file re-assembled from the three
+    per-segment predictions it produced - must be bit-exact (slicing, two Hann halves, overlap-add: no arithmetic but that)."""
+    from babe_amd.testing.long_file import assemble, cut_segments, plan_segments
+    s = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "formal_test_bwe.npz"))
+    L, segL, ola = int(s["L"]), 92092, int(s["OLA"])
+    plan = plan_segments(L, segL, 200, ola)
+    assert [p[0] for p in plan] == [int(v) for v in s["seg_starts"]]
+    segs = cut_segments(torch.from_numpy(s["degraded"])[0], segL, plan)
+    assert torch.equal(segs[:, ::16], torch.from_numpy(s["seg_in_sub16"]))      # what the reference fed predict_blind_bwe
+    out = assemble(torch.from_numpy(s["seg_pred"]), plan, L, segL, 200, ola)
+    assert torch.equal(out, torch.from_numpy(s["final"])[0])
+
 
 def test_checkpoint_conventions_and_wav_io(tmp_path):
     from babe_amd.io import ema_state_dict, read_audio_file, write_audio_file, write_filter_data

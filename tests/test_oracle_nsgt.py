@@ -54,3 +54,40 @@ def test_adjoint(cqt64):
     C2 = cqt64.fwd(x2)
     lhs = sum((c.real * g.real + c.imag * g.imag).sum() for c, g in zip(C2, G))
     assert abs(float(lhs) - float((x2 * gx).sum())) < 1e-8 * abs(float(lhs)) + 1e-8
+
+
+# ---- the pin that becomes active the day the library is present (tests/golden/make_cqt_golden.py) ----------------------------
+import os                                                                    # noqa: E402
+
+import numpy as np                                                           # noqa: E402
+
+CQT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cqt_lib.npz")
+
+
+def lib_probe(L, seed):
+    g = torch.Generator().manual_seed(seed)
+    return 0.1 * torch.randn(2, 1, L, generator=g)
+
+
+@pytest.mark.skipif(not os.path.exists(CQT_LIB), reason="tests/golden/cqt_lib.npz absent: cqt_nsgt_pytorch is not available in "
+                    "the build container (run tests/golden/make_cqt_golden.py where it is); the CQT is 'parity unpinned'")
+@pytest.mark.parametrize("fs,L", [(22050, 92092), (44100, 368368)])
+def test_oracle_vs_cqt_nsgt_pytorch_library(fs, L):
+    """oracle/nsgt.py against outputs of the reference's real dependency.  If this fails, the first suspect is the synthesis
+    convention (oracle/nsgt.py bwd: conjugate-mirrored bands added before the inverse FFT; the library is believed to irfft
+    the positive half only, SURVEY App. B 'pitfall'), then the relocated top bin / Nyquist band."""
+    z = np.load(CQT_LIB)
+    tag = f"{fs}_{L}"
+    sub = 8
+    cqt = CQT_nsgt(7, 64, "oct", ("kaiser", 1), fs, L)
+    x = lib_probe(L, int(z[f"{tag}.seed"]))
+    X = cqt.fwd(x)
+    assert [int(c.shape[-1]) for c in X] == [int(v) for v in z[f"{tag}.T_oct"]]
+    for j, c in enumerate(X):
+        got = torch.view_as_real(c.squeeze(1))[..., ::max(1, sub // 2), :]
+        ref = torch.from_numpy(z[f"{tag}.fwd{j}"])
+        assert float((got - ref).norm() / ref.norm()) < 1e-4, f"fwd octave {j}"
+    for name, y in (("bwd", cqt.bwd(X)), ("hpf", cqt.apply_hpf_DC(x.squeeze(1)))):
+        ref = torch.from_numpy(z[f"{tag}.{name}"])
+        got = y.reshape(2, -1)[:, ::sub]
+        assert float((got - ref).norm() / ref.norm()) < 1e-4, name
