@@ -38,3 +38,31 @@ def gather_results(x_local, fp_local, n_total=None):
     rows = [out[r * bmax: r * bmax + counts[r]] for r in range(world)]
     allr = torch.cat(rows, 0)
     return allr[:, :L].contiguous(), allr[:, L:].contiguous()
+
+
+def restore_clips_sharded(sampler, clips, seed=None):
+    """BASELINE configs[3]: n independent clips [n, Lc] (the same tensor on every rank, on the rank's GPU) are block-partitioned
+    over the ranks (shard_range; shards may differ by one clip), each rank restores its own - a clip = the segments of
+    long_file.plan_segments in ONE per-clip batch through sampler.predict_blind_bwe, cross-faded by long_file.assemble, exactly
+    what bench.py times - and ONE all_gather at the end hands every rank all n restored clips and filters in clip order.  No
+    communication before that.  seed: the noise of clip c is drawn from generators seeded with seed + c, so the result does
+    not depend on the number of ranks (row for row equal to a single-rank run: tests/test_gpu_dist.py)."""
+    from .testing.long_file import assemble, cut_segments, plan_segments
+    n, Lc = clips.shape
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    lo, hi = shard_range(n, rank, world)
+    segL = sampler.args.exp.audio_len
+    plan = plan_segments(Lc, segL)
+    xs, fps = [], []
+    for c in range(lo, hi):
+        if seed is not None:
+            torch.manual_seed(seed + c)
+            torch.cuda.manual_seed(seed + c)
+        x, fp = sampler.predict_blind_bwe(cut_segments(clips[c], segL, plan))
+        xs.append(assemble(x, plan, Lc, segL))
+        fps.append(fp.reshape(-1))
+    P = 2 * len(plan) * len(sampler.args.tester.blind_bwe.initial_conditions.fc)
+    x_local = torch.stack(xs) if xs else torch.zeros(0, Lc, device=clips.device)
+    fp_local = torch.stack(fps) if fps else torch.zeros(0, P, device=clips.device)
+    return gather_results(x_local, fp_local)

@@ -75,25 +75,33 @@ def cpu_baseline():
     """SURVEY 8d protocol.  The oracle (CPU restatement of the reference, pinned at FULL width against the imported
     reference by tests/golden/unet_full_46046.npz) runs T=2 of the sampler = 3 score evaluations after one warm-up
     evaluation, on a 46046-sample segment at 44.1 kHz (1/8 of the 368368-sample segment: the work is proportional to
-    the number of CQT frames, i.e. identical cost per audio-second), full-width network; extrapolated x69/3.  Timed at
-    n = min(16, logical CPUs) threads (the headline `value`; with hundreds of threads the many small ops of the
-    reference path get slower) and at n = 8 (comparable with the survey's numbers), with the per-component split."""
+    the number of CQT frames, i.e. identical cost per audio-second), full-width network; extrapolated x69/3.  Three thread
+    counts: ALL PHYSICAL CORES of the host (count stated; what 8d asks for), 16 (the fastest setting measured on the 128-core
+    hosts of this pool: the many small ops of the reference path do not scale past a few tens of threads - the all-cores
+    leg is the number that shows it) and 8 (comparable with the survey's numbers), each with the per-component split; the
+    headline `value` / `cores` is the BEST of the three, the others are beside it.  Plus ONE evaluation at the benchmark's
+    own geometry (368368 samples, no extrapolation in length) at the best thread count, so that the x8 length scaling of the
+    short sample is a measured number."""
     from oracle import edm as E
     from oracle import unet as UN
     from oracle.nsgt import CQT_nsgt as OracleCQT
     from oracle.sampler import OracleBlindSampler
     from babe_amd.networks.cqtdiff_plus import init_state_dict
-    L = 46046
     Ns, nd = [64, 96, 96, 128, 128, 256, 256], [2, 3, 4, 5, 6, 7, 7]
     sd = init_state_dict(Ns, nd, seed=0, gate_scale=1.0)
-    cqt = OracleCQT(7, 64, "oct", ("kaiser", 1), FS, L)
     cfg = dict(num_octs=7, bins_per_oct=64, num_dils=nd)
-    net = lambda x, cn: UN.unet_forward(sd, cfg, cqt, x, cn)
-    smp = OracleBlindSampler(net, cqt, E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10), fs=FS, audio_len=L, T=2)
-    g = torch.Generator().manual_seed(0)
-    y = 0.1 * torch.randn(1, L, generator=g)
-    x = y + 0.2 * torch.randn(1, L, generator=g)
-    sched = E.schedule(smp.p, 2, 0.2)
+
+    def setup(L):
+        cqt = OracleCQT(7, 64, "oct", ("kaiser", 1), FS, L)
+        net = lambda x, cn: UN.unet_forward(sd, cfg, cqt, x, cn)
+        smp = OracleBlindSampler(net, cqt, E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10), fs=FS, audio_len=L, T=2)
+        g = torch.Generator().manual_seed(0)
+        y = 0.1 * torch.randn(1, L, generator=g)
+        x = y + 0.2 * torch.randn(1, L, generator=g)
+        return smp, x, y, E.schedule(smp.p, 2, 0.2)
+
+    L = 46046
+    smp, x, y, sched = setup(L)
 
     def run(threads):
         torch.set_num_threads(threads)
@@ -106,18 +114,42 @@ def cpu_baseline():
         return (time.perf_counter() - t0) / 3, {k: round(v / 3, 4) for k, v in timers.items()}
 
     logical = os.cpu_count() or 1
-    n_main = min(16, logical)
-    dt, split = run(n_main)
-    out = {"value": (L / FS) / (69 * dt), "unit": "audio-sec/s", "cores": n_main, "kind": "port",
+    phys = physical_cores() or logical
+    legs = {}
+    for n in sorted({min(phys, logical), min(16, logical), min(8, logical)}):
+        dt, split = run(n)
+        legs[n] = {"threads": n, "seconds_per_evaluation": round(dt, 4), "split_seconds_per_evaluation": split,
+                   "value": (L / FS) / (69 * dt)}
+    best = max(legs, key=lambda n: legs[n]["value"])
+    dt = legs[best]["seconds_per_evaluation"]
+    out = {"value": legs[best]["value"], "unit": "audio-sec/s", "cores": best, "kind": "port",
            "physical_cores": physical_cores(), "logical_cpus": logical,
-           "seconds_per_evaluation": round(dt, 4), "split_seconds_per_evaluation": split,
+           "seconds_per_evaluation": dt, "split_seconds_per_evaluation": legs[best]["split_seconds_per_evaluation"],
            "sample": f"T=2 (3 score evaluations after 1 warm-up evaluation: UNet fwd + input-VJP, filter fit, filter apply) "
                      f"of a {L}-sample segment at 44.1 kHz (1/8 of the 368368-sample segment, same cost per audio-second), "
-                     f"full-width network, {3 * dt:.1f} s on {n_main} threads, extrapolated x69/3"}
-    if n_main != 8 and logical >= 8:
-        dt8, split8 = run(8)
-        out["value_8_threads"] = (L / FS) / (69 * dt8)
-        out["split_seconds_per_evaluation_8_threads"] = split8
+                     f"full-width network, {3 * dt:.1f} s on {best} threads (the best of {sorted(legs)} threads; all-physical-cores "
+                     f"leg = {min(phys, logical)} threads), extrapolated x69/3",
+           "legs": [legs[n] for n in sorted(legs)]}
+    if 8 in legs and best != 8:
+        out["value_8_threads"] = legs[8]["value"]
+    pc = min(phys, logical)
+    if pc in legs:
+        out["value_all_physical_cores"] = legs[pc]["value"]
+    # one evaluation at the benchmark's own segment length (no length extrapolation), best thread count, no warm-up
+    try:
+        torch.set_num_threads(best)
+        smpF, xF, yF, schedF = setup(SEG)
+        params = torch.tensor([list(smpF.fc_init), list(smpF.A_init)], dtype=torch.float32)
+        timers = {}
+        t0 = time.perf_counter()
+        smpF.evaluate(xF, schedF[0], yF, params, blind=True, timers=timers)
+        dtF = time.perf_counter() - t0
+        out["full_segment_evaluation"] = {"segment_len": SEG, "threads": best, "seconds": round(dtF, 3),
+                                          "split_seconds": {k: round(v, 4) for k, v in timers.items()},
+                                          "value": (SEG / FS) / (69 * dtF),
+                                          "ratio_to_8x_short_sample": round(dtF / (8 * dt), 3)}
+    except Exception as e:                                                   # (host memory: ~26 GB)  noqa: BLE001
+        out["full_segment_evaluation"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

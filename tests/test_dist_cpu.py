@@ -55,3 +55,53 @@ def test_gather_world2_gloo():
     for rank, xs, fs in res:
         assert xs == [float(c) for c in range(n_clips)]
         assert fs == [100.0 * c for c in range(n_clips)]
+
+
+class _StubSampler:
+    """predict_blind_bwe stand-in for the host-logic test: 'restores' a segment by adding 1 and reports its mean as filter."""
+
+    def __init__(self):
+        import types
+        ic = types.SimpleNamespace(fc=[1.0, 2.0])
+        self.args = types.SimpleNamespace(exp=types.SimpleNamespace(audio_len=1000),
+                                          tester=types.SimpleNamespace(blind_bwe=types.SimpleNamespace(initial_conditions=ic)))
+
+    def predict_blind_bwe(self, y):
+        noise = torch.randn(y.shape)                      # (seeded per clip by restore_clips_sharded)
+        return y + 1.0 + noise, torch.stack([y.mean(1, keepdim=True).expand(-1, 2), y.std(1, keepdim=True).expand(-1, 2)], 1)
+
+
+def _worker_restore(rank, world, port, q):
+    from babe_amd.dist import restore_clips_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    clips = torch.randn(3, 1700, generator=torch.Generator().manual_seed(3))
+    x, fp = restore_clips_sharded(_StubSampler(), clips, seed=10)
+    q.put((rank, x.numpy().copy(), fp.numpy().copy()))          # (by value: the producer exits before the consumer reads)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_restore_clips_sharded_world2_equals_world1():
+    """3 clips on 2 ranks (shards of 2 and 1) through the product's sharded driver: segmentation, per-clip seeding, padding
+    of the uneven shard and the gather give every rank the single-rank result, row for row."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p0 = ctx.Process(target=_worker_restore, args=(0, 1, _free_port(), q))
+    p0.start()
+    _, x1, f1 = q.get(timeout=120)
+    p0.join(60)
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_restore, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert x1.shape == (3, 1700) and f1.shape == (3, 8)
+    for _, x2, f2 in res:
+        assert (x2 == x1).all() and (f2 == f1).all()
