@@ -7,6 +7,7 @@
 #include "fft_lds.h"
 #include "../../include/babe_hip.h"
 #include "prof.h"
+#include <cstdlib>
 
 namespace {
 
@@ -411,6 +412,268 @@ __global__ __launch_bounds__(256) void filter_fit_kernel(const double* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast variant of the fit (round 4): same projected gradient descent, same statistics, same update rule and early exit, built
+// for LATENCY - the kernel is one workgroup on every evaluation's critical path (138 calls per benchmark step).
+// What the first kernel paid per iteration (17 us): three workgroup barriers around two single-thread sections (the anchor
+// chain with K powf / log2f / divisions; the K-parameter update), 8 bins per thread with powf + 2 log2f + 2 divisions each,
+// and the statistics re-read from L2 every iteration.  Here:
+//  * 256 threads = ONE wave per SIMD (every wave executes the serial sections redundantly, and two waves of a SIMD would
+//    share its one vector issue slot: 512 threads measured 594 us per 100 iterations, 6 us each), at most 10 bins per thread,
+//    whose three statistics, weight and log2(f) live in REGISTERS for all iterations;
+//  * H_k = exp2(A_s * (log2 f_k - log2 fc_s) * log2(10)/20) * anchor_s on the hardware's v_exp_f32 / v_log_f32 (1 ulp; the
+//    libm powf / log2f of the first kernel differ from the reference's CPU libm by as much - the reference's own H carries
+//    ~1e-6 relative rounding noise at 50 dB of attenuation - so this changes the noise realisation, not its size; the filter
+//    that is APPLIED is still designed by design_filter_kernel with the reference's operation order and exact masks);
+//  * no single-thread section: the anchor chain and the parameter update are computed redundantly by every lane from
+//    wave-uniform data; ONE barrier per iteration (per-wave partial sums in a double-buffered LDS array, every wave adds
+//    the eight partials in the same order, so all waves hold bit-identical parameters).
+// Segment masks use the exact float32 comparisons `f >= fc` of the reference, as before.
+constexpr int FIT_NT = 256, FIT_NB = 10;                // threads, bins per thread (nbins <= 2560: NFFT <= 4096 + 1024)
+
+// first_bin_ge with a multiplication for the initial guess (the two correction loops make the result exact whatever the guess)
+__device__ __forceinline__ int first_bin_ge_mul(float fc, float df, float inv_df, int nbins) {
+    int k = (int)floorf(fc * inv_df);
+    k = k < 0 ? 0 : (k > nbins - 1 ? nbins - 1 : k);
+    while (k > 0 && (float)(k - 1) * df >= fc) --k;
+    while (k < nbins && (float)k * df < fc) ++k;
+    return k;
+}
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+// Sum over the 64 lanes of a wave without LDS round trips: four DPP row shifts give lane 15 of every 16-lane row its row's
+// total (inclusive scan), v_readlane fetches the four row totals, which are added in a fixed order: the result is wave-uniform
+// (and lives in scalar registers).  ds_bpermute butterflies (wave_sum) cost six LDS latencies per value.
+__device__ __forceinline__ double dpp_row_shr_add(double v, int sh) {
+    int lo = __double2loint(v), hi = __double2hiint(v), lo2, hi2;
+    switch (sh) {
+        case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); break;
+        case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); break;
+        case 4: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); break;
+        default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); break;
+    }
+    return v + __hiloint2double(hi2, lo2);            // (bound_ctrl: lanes shifted in from outside the row read 0)
+}
+__device__ __forceinline__ double wave_sum_uniform(double v) {
+    v = dpp_row_shr_add(v, 1);
+    v = dpp_row_shr_add(v, 2);
+    v = dpp_row_shr_add(v, 4);
+    v = dpp_row_shr_add(v, 8);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        t[r] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r + 15), __builtin_amdgcn_readlane(lo, 16 * r + 15));
+    return (t[0] + t[1]) + (t[2] + t[3]);
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int K>                                        // (compile-time K: the K-loops are straight-line code, no predicates)
+__global__ __launch_bounds__(FIT_NT) void filter_fit_fast_kernel(const double* __restrict__ stats, float* __restrict__ params,
+                                                                  int* __restrict__ n_iter, int nbins, float df,
+                                                                  babe_fit_cfg cfg) {
+    constexpr int KMAX = K;                              // (shadows the file-wide bound inside this kernel)
+    constexpr int NW = FIT_NT / 64, NV = 2 * KMAX + 1;
+    __shared__ double red[2][NW][NV];
+    const int p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* Sxx = stats + ((long)p * 3 + 0) * nbins;
+    const double* Sxy = stats + ((long)p * 3 + 1) * nbins;
+    const double* Syy = stats + ((long)p * 3 + 2) * nbins;
+    constexpr float C20 = 0.16609640474436813f;          // log2(10) / 20
+    const float inv_df = 1.f / df;
+    const double cln = 0.11512925464970228;              // ln(10) / 20
+    // per-thread bins k = tid + 512 m: statistics pre-multiplied by the weight, frequency and its log2
+    double sxx[FIT_NB], sxy[FIT_NB], syy[FIT_NB];
+    float fk[FIT_NB], l2f[FIT_NB];
+#pragma unroll
+    for (int m = 0; m < FIT_NB; ++m) {
+        const int k = tid + FIT_NT * m;
+        const bool ok = k < nbins;
+        const double w2 = ok ? (double)weight_sq(k, nbins, cfg.weighting) : 0.0;
+        sxx[m] = ok ? w2 * Sxx[k] : 0.0;
+        sxy[m] = ok ? w2 * Sxy[k] : 0.0;
+        syy[m] = ok ? w2 * Syy[k] : 0.0;
+        fk[m] = (float)k * df;
+        l2f[m] = fast_log2(fk[m]);                       // (k = 0: -inf, never used: f = 0 lies below every breakpoint)
+    }
+    float fc[KMAX], A[KMAX], anchor[KMAX], l2fc[KMAX], prev_fc[KMAX], prev_A[KMAX];
+    int kstar[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+        fc[i] = i < K ? params[((long)p * 2 + 0) * K + i] : 3.0e38f;      // (unused breakpoints: above every bin)
+        A[i] = i < K ? params[((long)p * 2 + 1) * K + i] : 0.f;
+        prev_fc[i] = prev_A[i] = 0.f;
+        anchor[i] = 1.f;
+        l2fc[i] = 0.f;
+        kstar[i] = nbins;
+    }
+    int it = 0;
+    for (; it < cfg.max_iter; ++it) {
+        // ---- anchors (build_filter): every lane, wave-uniform data
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i)
+            if (i < K) {
+                l2fc[i] = fast_log2(fc[i]);
+                kstar[i] = first_bin_ge_mul(fc[i], df, inv_df, nbins);
+            }
+        anchor[0] = 1.f;
+#pragma unroll
+        for (int i = 1; i < KMAX; ++i)
+            if (i < K) {
+                const float fq = (float)(kstar[i] < nbins ? kstar[i] : nbins - 1) * df;
+                // segment that wrote H at that bin before segment i did: the last j < i with fq >= fc[j] searched downwards as
+                // build_filter does (j = i - 1, stepping down while fq < fc[j] and j > 0)
+                float fcj = fc[0], Aj = A[0], aj = anchor[0], lj = l2fc[0];
+                bool found = false;
+#pragma unroll
+                for (int j = KMAX - 1; j >= 1; --j)
+                    if (j < i && !found && !(fq < fc[j])) {
+                        fcj = fc[j]; Aj = A[j]; aj = anchor[j]; lj = l2fc[j];
+                        found = true;
+                    }
+                anchor[i] = (fq < fcj) ? 1.f : fast_exp2(Aj * (fast_log2(fq) - lj) * C20) * aj;
+            }
+        // ---- per-bin pass.  H_k = 2^(P_s l2f_k + Q_s) with P_s = c A_s, Q_s = log2(anchor_s) - P_s log2(fc_s): two selected
+        // values per bin; Ep = sum e (l2f_k - log2 fc_s) is accumulated as sum e l2f_k and corrected by log2(fc_s) E_s after the
+        // workgroup sums (the subtraction moves out of the loop; same value up to rounding of the double sums)
+        float Pq[KMAX], Qq[KMAX];
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            Pq[i] = C20 * A[i];
+            Qq[i] = fast_log2(anchor[i]) - Pq[i] * l2fc[i];
+        }
+        double E[KMAX], Ep[KMAX], loss2 = 0;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) E[i] = Ep[i] = 0;
+#pragma unroll
+        for (int m = 0; m < FIT_NB; ++m) {
+            const float f = fk[m];
+            int sidx = -1;
+            float Ps = 0.f, Qs = 0.f;
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i)
+                if (f >= fc[i]) {                        // later breakpoints overwrite earlier ones (seg_of)
+                    sidx = i; Ps = Pq[i]; Qs = Qq[i];
+                }
+            const double Hk = sidx >= 0 ? (double)fast_exp2(Ps * l2f[m] + Qs) : 1.0;
+            const double hx = Hk * sxx[m];
+            loss2 += Hk * hx - 2.0 * Hk * sxy[m] + syy[m];
+            const double e = sidx >= 0 ? (hx - sxy[m]) * Hk * cln : 0.0;
+            const double el = sidx >= 0 ? e * (double)l2f[m] : 0.0;
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i)
+                if (i == sidx) {
+                    E[i] += e;
+                    Ep[i] += el;
+                }
+        }
+        // ---- workgroup sums: DPP wave sums (uniform), per-wave partials through LDS, ONE barrier; then lane v < 2K + 1 of every
+        // wave adds the eight partials of value v (same order in every wave) and v_readlane broadcasts the totals
+        loss2 = wave_sum_uniform(loss2);
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            E[i] = wave_sum_uniform(E[i]);
+            Ep[i] = wave_sum_uniform(Ep[i]);
+        }
+        double (*rb)[NV] = red[it & 1];
+        {
+            double mine = loss2;                              // lane v keeps value v of this wave
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) {
+                mine = lane == 1 + i ? E[i] : mine;
+                mine = lane == 1 + KMAX + i ? Ep[i] : mine;
+            }
+            if (lane < NV) rb[wave][lane] = mine;
+        }
+        __syncthreads();
+        double tot = 0;
+        if (lane < NV) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += rb[w][lane];
+        }
+        const int tlo = __double2loint(tot), thi = __double2hiint(tot);
+        auto total = [&](int v) __attribute__((always_inline)) {
+            return __hiloint2double(__builtin_amdgcn_readlane(thi, v), __builtin_amdgcn_readlane(tlo, v));
+        };
+        const double l2 = total(0);
+        double Et[KMAX], Ept[KMAX];
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            Et[i] = total(1 + i);
+            Ept[i] = total(1 + KMAX + i) - (double)l2fc[i] * Et[i];
+        }
+        // ---- parameter update (fit_params :561-590), every lane
+        // (1 / loss and A / (fc ln 2) in float: the products are rounded to float before they are used, :568-570 of the reference)
+        const float lossf = sqrtf(l2 > 0 ? (float)l2 : 0.f);
+        const double il = lossf > 0 ? (double)(1.f / lossf) : 0.0;
+        double suf[KMAX + 1];
+        suf[KMAX] = 0;
+#pragma unroll
+        for (int i = KMAX - 1; i >= 0; --i) suf[i] = suf[i + 1] + (i < K ? Et[i] : 0.0);
+        float nfc[KMAX], nA[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            nfc[j] = fc[j];
+            nA[j] = A[j];
+            if (j < K) {
+                double Lj = 0;
+                if (j + 1 < KMAX && j + 1 < K) {
+                    const int ks = kstar[j + 1] < nbins ? kstar[j + 1] : nbins - 1;
+                    Lj = (double)(fast_log2((float)ks * df) - l2fc[j]);
+                }
+                const double gA = (Ept[j] + Lj * suf[j + 1]) * il;
+                const double gfc = (double)(-A[j] / (fc[j] * 0.6931471805599453f)) * suf[j] * il;
+                nfc[j] = fc[j] - cfg.mu_fc * (float)gfc;
+                nA[j] = A[j] - cfg.mu_A * (float)gA;
+            }
+        }
+        if (cfg.clamp_fc) {
+            nfc[0] = fminf(fmaxf(nfc[0], cfg.fcmin), cfg.fcmax);
+#pragma unroll
+            for (int j = 1; j < KMAX; ++j)
+                if (j < K) nfc[j] = fminf(fmaxf(nfc[j], nfc[j - 1] + 1.f), cfg.fcmax);
+        }
+        if (cfg.clamp_A) {
+            nA[0] = fminf(fmaxf(nA[0], cfg.Amin), cfg.only_negative_A ? -1.f : cfg.Amax);
+#pragma unroll
+            for (int j = 1; j < KMAX; ++j)
+                if (j < K) nA[j] = fminf(fmaxf(nA[j], cfg.Amin), cfg.only_negative_A ? nA[j - 1] : cfg.Amax);
+        }
+        bool done = false;
+        if (it > 0) {
+            float dfc = 0, dA = 0;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j)
+                if (j < K) {
+                    dfc += fabsf(nfc[j] - prev_fc[j]);
+                    dA += fabsf(nA[j] - prev_A[j]);
+                }
+            done = dfc / K < cfg.tol_fc && dA / K < cfg.tol_A;
+        }
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            if (j < K) {
+                fc[j] = nfc[j];
+                A[j] = nA[j];
+                prev_fc[j] = nfc[j];
+                prev_A[j] = nA[j];
+            }
+        if (done) {                                      // (wave-uniform AND workgroup-uniform: identical data in every lane)
+            ++it;
+            break;
+        }
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i)
+            if (i < K) {
+                params[((long)p * 2 + 0) * K + i] = fc[i];
+                params[((long)p * 2 + 1) * K + i] = A[i];
+            }
+        if (n_iter) n_iter[p] = it;
+    }
+}
+
 int ilog2_exact(int n) {
     int l = 0;
     while ((1 << l) < n) ++l;
@@ -514,8 +777,20 @@ extern "C" int babe_filter_fit(const double* stats, float* params, int* n_iter, 
     BABE_CHECK_ARG(stats && params && cfg && P > 0 && K > 0 && K <= KMAX && nbins > 1, "filter_fit: bad arguments");
     BabeProfScope prof(BABE_SLOT_FILTER_FIT, 24.0 * P * (double)nbins, 0, 0, stream);
     const float df = fs / (float)nfft;
-    hipLaunchKernelGGL(filter_fit_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, stats, params, n_iter, K, nbins,
-                       df, *cfg);
+    static const char* ov = getenv("BABE_FIT_FAST");
+    if (nbins <= FIT_NT * FIT_NB && !(ov && ov[0] == '0')) {
+#define FIT_CASE(k)                                                                                                      \
+    case k:                                                                                                              \
+        hipLaunchKernelGGL(filter_fit_fast_kernel<k>, dim3(P), dim3(FIT_NT), 0, (hipStream_t)stream, stats, params, n_iter, \
+                           nbins, df, *cfg);                                                                             \
+        break;
+        switch (K) {
+            FIT_CASE(1) FIT_CASE(2) FIT_CASE(3) FIT_CASE(4) FIT_CASE(5) FIT_CASE(6) FIT_CASE(7) FIT_CASE(8)
+        }
+#undef FIT_CASE
+    } else
+        hipLaunchKernelGGL(filter_fit_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, stats, params, n_iter, K, nbins,
+                           df, *cfg);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

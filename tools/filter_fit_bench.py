@@ -19,3 +19,10 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 p = p0.clone()
 e0.record(); nit = st.filter_fit(stats, p, cfg); e1.record(); torch.cuda.synchronize()
 print(f"filter_fit (K={K}): {e0.elapsed_time(e1)*1e3:.0f} us for {int(nit[0])} iterations -> fc={[round(float(v), 2) for v in p[0,0]]} Hz A={[round(float(v), 4) for v in p[0,1]]} dB")
+# trajectory: parameters after n iterations (compare BABE_FIT_FAST=0 / 1 runs of this script)
+for n in (1, 2, 3, 5, 10, 20, 40):
+    cfgn = make_fit_cfg(tol=(0.0, 0.0), max_iter=n) if "max_iter" in make_fit_cfg.__code__.co_varnames else None
+    if cfgn is None:
+        break
+    p = p0.clone(); st.filter_fit(stats, p, cfgn); torch.cuda.synchronize()
+    print(f"  after {n:3d}: fc={[round(float(v), 3) for v in p[0,0]]} A={[round(float(v), 5) for v in p[0,1]]}")
