@@ -114,6 +114,16 @@ def factor_len(L):
     return N1, N2
 
 
+def small_radices(N):
+    """N as a product of at most 6 radices of csrc/fft_mixed.hip (4 preferred over 2 x 2, large radices last), or None."""
+    out, n = [], N
+    for r in (4, 2, 3, 5, 7, 11, 13, 23):
+        while n % r == 0 and not (r == 2 and n % 4 == 0):
+            out.append(r)
+            n //= r
+    return out if (n == 1 and 1 <= len(out) <= 6) else None
+
+
 DFT_SLOT = 5        # BABE_SLOT_DFT_STAGE (csrc/prof.h)
 
 
@@ -132,6 +142,8 @@ def _register_sigs():
     L = lib()
     P, I, F, Lg = C.c_void_p, C.c_int, C.c_float, C.c_long
     L.babe_fft_twiddle_transpose.argtypes = [P, P, P, I, I, I, I, P]
+    L.babe_rfft_mixed.argtypes = [P, P, P, P, P, I, I, I, I, P, I, P, I, P, P, P, I, P]
+    L.babe_rfft_mixed.restype = C.c_int
     L.babe_cqt_band_analysis.argtypes = [C.POINTER(_BandsStruct), P, P, I, P]
     L.babe_cqt_band_synthesis.argtypes = [C.POINTER(_BandsStruct), P, P, Lg, I, P]
     L.babe_cqt_gather.argtypes = [P, Lg, P, P, P, P, I, I, F, P, I, P]
@@ -170,6 +182,16 @@ class RealFFT:
         self.W1b, self.W3b = ops.PackedConv(t(W1).reshape(2 * N1, N1, 1, 1)), ops.PackedConv(t(W3).reshape(2 * K2, 2 * N2, 1, 1))
         self.tw = t(tw).contiguous()
         self.dev = device
+        # Mixed-radix plan (csrc/fft_mixed.hip): both factors as products of the radices the Stockham kernel has; otherwise
+        # (or with BABE_FFT_MIXED=0) the dense DFT stages above are used
+        self.rad1, self.rad2 = small_radices(N1), small_radices(N2)
+        self.mixed = (self.rad1 is not None and self.rad2 is not None and max(N1, N2) <= 1077 and
+                      os.environ.get("BABE_FFT_MIXED", "1") != "0")
+        if self.mixed:
+            wN = lambda N: t(np.stack([np.cos(2 * np.pi * np.arange(N) / N), -np.sin(2 * np.pi * np.arange(N) / N)], -1)).contiguous()
+            self.w1, self.w2 = wN(N1), wN(N2)
+            self.rad1_c = (C.c_int * len(self.rad1))(*self.rad1)
+            self.rad2_c = (C.c_int * len(self.rad2))(*self.rad2)
 
     def rfft(self, x, out=None):
         """x [B,L] -> planar spectrum [B,2,KX] (bins above L/2 hold valid but redundant values)."""
@@ -188,9 +210,23 @@ class RealFFT:
         finally:
             lib().babe_prof_conv_slot(-1)
 
+    def _mixed(self, x_in, spec_out, spec_in, x_out, B, direction):
+        work = torch.empty(B, 2, self.L, device=self.dev)
+        check(lib().babe_rfft_mixed(ptr(x_in) if x_in is not None else None, ptr(spec_out) if spec_out is not None else None,
+                                    ptr(spec_in) if spec_in is not None else None, ptr(x_out) if x_out is not None else None,
+                                    ptr(work), B, self.N1, self.N2, self.K2, self.rad1_c, len(self.rad1), self.rad2_c,
+                                    len(self.rad2), ptr(self.w1), ptr(self.w2), ptr(self.tw), direction, stream()), "rfft_mixed")
+
     def _rfft(self, x, out=None):
         B = x.shape[0]
         N1, N2, K2 = self.N1, self.N2, self.K2
+        if self.mixed:
+            x = x.reshape(B, self.L)
+            x = x if x.is_contiguous() else x.contiguous()
+            if out is None:
+                out = torch.empty(B, 2, self.KX, device=self.dev)
+            self._mixed(x, out, None, None, B, 0)
+            return out
         self.W1, self.W3 = (self.W1s, self.W3s) if B < 4 else (self.W1b, self.W3b)
         A = torch.empty(B, 2 * N1, 1, N2, device=self.dev)
         ops.conv2d(x.reshape(B, N1, 1, N2), self.W1, A)
@@ -204,6 +240,12 @@ class RealFFT:
     def _rfft_T(self, spec, out=None):
         B = spec.shape[0]
         N1, N2, K2 = self.N1, self.N2, self.K2
+        if self.mixed:
+            spec = spec if spec.is_contiguous() else spec.contiguous()
+            if out is None:
+                out = torch.empty(B, self.L, device=self.dev)
+            self._mixed(None, None, spec, out, B, 1)
+            return out
         self.W1, self.W3 = (self.W1s, self.W3s) if B < 4 else (self.W1b, self.W3b)
         At = torch.empty(B, 2 * N2, 1, N1, device=self.dev)
         ops.conv2d(spec.view(B, 2 * K2, 1, N1), self.W3, At, transpose=True)

@@ -158,6 +158,14 @@ int babe_rff(const float* cnoise, const float* freq, float* out, int B, int R, v
  * k = k1 + N1*k2 stored as [K2][N1] (natural order), KX = K2*N1 >= L/2+1. */
 /* forward: in [B][2*N1][N2] (Re rows k1 then Im rows) -> out [B][2*N2][N1] = transpose(in * tw[k1][n2]);
  * adjoint=1: in [B][2*N2][N1] -> out [B][2*N1][N2] = transpose(in) * conj(tw). tw: [N1][N2] float2. */
+/* Mixed-radix variant (csrc/fft_mixed.hip, round 4): the same four-step transform with both stages as Stockham FFTs of
+ * length N1 / N2 in LDS (radices 2,3,4,5,7,11,13,23) - two launches per transform, no dense DFT matrices.  direction 0:
+ * x_in [B][N1*N2] -> spec_out planar [B][2][K2*N1];  direction 1: the transpose, spec_in -> x_out (real part of the unnormalised
+ * inverse DFT of the zero-padded half spectrum).  rad1 / rad2: radices whose product is N1 / N2 (at most 6 each); w1 / w2:
+ * exp(-2 pi i j / N1|N2) as float2[N]; tw: [N1][N2] float2 exp(-2 pi i k1 n2 / L); work: [B][2][N1*N2] floats of scratch. */
+int babe_rfft_mixed(const float* x_in, float* spec_out, const float* spec_in, float* x_out, float* work, int B, int N1,
+                    int N2, int K2, const int* rad1, int nrad1, const int* rad2, int nrad2, const float* w1, const float* w2,
+                    const float* tw, int direction, void* stream);
 int babe_fft_twiddle_transpose(const float* in, float* out, const float* tw, int B, int N1, int N2,
                                int adjoint, void* stream);
 typedef struct {

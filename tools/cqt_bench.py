@@ -47,4 +47,9 @@ for B in [int(v) for v in os.environ.get("BS", "1,2,8,32,64").split(",")]:
     print(f"B={B:3d} [GPU time, HIP events] band_analysis {g_an:7.1f} us = {tb(g_an):5.2f} TB/s ({tb(g_an) / 8 * 100:4.1f}% of 8 TB/s) | "
           f"band_synthesis {g_sy:7.1f} us + gather {g_ga:6.1f} us = {tb(g_sy + g_ga):5.2f} TB/s ({tb(g_sy + g_ga) / 8 * 100:4.1f}%) "
           f"[band_synthesis alone {tb(g_sy):5.2f} TB/s] | rfft_L: 2 DFT stages {g_dft:6.1f} us each + twiddle_transpose {g_tt:6.1f} us")
-    print(f"B={B:3d} [Python loop, wall]    analysis {t_an*1e3:8.1f} us | synthesis(+gather) {t_sy*1e3:8.1f} us | rfft_L {t_fft*1e3:8.1f} us")
+    t_fftT = timeit(lambda: cq.fft.rfft_T(spec))
+    print(f"B={B:3d} [Python loop, wall]    analysis {t_an*1e3:8.1f} us | synthesis(+gather) {t_sy*1e3:8.1f} us | rfft_L {t_fft*1e3:8.1f} us | rfft_L^T {t_fftT*1e3:8.1f} us  (mixed-radix: {getattr(cq.fft, 'mixed', False)})")
+    # whole transforms (what the UNet calls): fwd = rfft_L + band analysis; algorithmic bytes = signal in + coefficients out
+    t_fwd = timeit(lambda: cq.fwd_planar(x))
+    by_fwd = B * (L * 4 + ncoef * 8)
+    print(f"B={B:3d} [whole CQT.fwd, wall] {t_fwd*1e3:8.1f} us = {by_fwd / t_fwd / 1e9:6.3f} TB/s on {by_fwd / B / 1e6:.2f} MB per clip ({by_fwd / t_fwd / 1e9 / 8 * 100:4.1f}% of 8 TB/s)")
