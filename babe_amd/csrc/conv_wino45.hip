@@ -901,8 +901,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, 
 // slot are issued in the last group of the previous one: slot 1 at g2 (its last chunk was issued at g8 of the previous
 // super-slab: 13 younger operations), slot 2 at g5 (g11 of the previous one: 13), slot 3 at g8 (g2: 7), slot 0 of the next
 // super-slab at g11 (g5: 6).
+// (-DBABE_W45X_NUM_VGPR=96 caps the kernel at 192 registers - the attribute counts halves of the unified file - so that two
+// 64-register waves of the other lane's element-wise kernels would fit beside the two conv waves of a SIMD.  Measured, round 4,
+// same box: 76-136 spilled registers, a few of them inside the loop, whole-job throughput 1.44 instead of 2.06 audio-sec/s.
+// Default 128 = no cap.)
+#ifndef BABE_W45X_NUM_VGPR
+#define BABE_W45X_NUM_VGPR 128
+#endif
 template <bool HAS_ISC, int BN>
-__global__ __launch_bounds__(512, 1) void conv_wino45x_kernel(babe_conv_args a, Wino45Geom g, const float* __restrict__ wq) {
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NUM_VGPR))) void conv_wino45x_kernel(babe_conv_args a, Wino45Geom g, const float* __restrict__ wq) {
 #if __HIP_DEVICE_COMPILE__
     constexpr int KS = 16, KQ = 4, NU = 32;
     static_assert(BN == 128 || BN == 96, "tile width");
