@@ -125,8 +125,9 @@ class BlindSampler:
     def _lane_kw(self, lane):
         return {"lane": lane} if (lane is not None and getattr(self.model, "supports_lanes", False)) else {}
 
-    def get_denoised_estimate(self, x, t, lane=None):
-        """x [B,L] device, t host float -> hpf_DC(denoiser(x))  (:152-157); keeps the UNet context for the VJP."""
+    def get_denoised_estimate(self, x, t, lane=None, hpf=True):
+        """x [B,L] device, t host float -> hpf_DC(denoiser(x))  (:152-157); keeps the UNet context for the VJP.
+        hpf=False: without the DC / Nyquist high-pass (the unguided replacement branch of edm_sampler.py:124-130 has none)."""
         dp = self.diff_params
         s = torch.as_tensor(t, dtype=torch.float32)
         self._c = (float(dp.cskip(s)), float(dp.cout(s)), float(dp.cin(s)))
@@ -137,7 +138,7 @@ class BlindSampler:
         # pageable H2D copy in the loop would stall the host on this stream and starve the other lanes)
         net = self.model.fwd_nograd(xin, cn, **self._lane_kw(lane))
         xd = lincomb(torch.empty_like(x), cskip, x, cout, net)
-        if self.args.tester.filter_out_cqt_DC_Nyq:
+        if hpf and self.args.tester.filter_out_cqt_DC_Nyq:
             xd = self.model.CQTransform.apply_hpf_DC(xd)
         return xd
 

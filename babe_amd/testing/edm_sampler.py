@@ -26,11 +26,11 @@ class Sampler(BlindSampler):
             self.update_diff_params()
         self.order = args.tester.order
         self.xi = args.tester.posterior_sampling.xi
-        self.data_consistency = args.tester.posterior_sampling.data_consistency
-        if self.data_consistency:
-            raise NotImplementedError("data_consistency=True (replacement step) is not on the HIP path")
-        if self.xi <= 0:
-            raise NotImplementedError("xi=0 (no guidance)")
+        # posterior_sampling.data_consistency (:47-54, :113-122): after the guided score, the replacement step
+        # x0 <- y + x0 - A(x0) on the Tweedie estimate - BlindSampler.evaluate's classic branch with the FIR as A.
+        # xi = 0 (:124-130): no guidance at all, the replacement step on the plain denoised estimate (evaluate below).
+        self.data_consistency = bool(args.tester.posterior_sampling.data_consistency)
+        self._dc_cfg = self.data_consistency
         self.nb_steps = args.tester.T
         self.rid = rid
         self.batch_semantics = batch_semantics
@@ -46,6 +46,15 @@ class Sampler(BlindSampler):
             from ..stft import STFTOps
             self._stft = STFTOps(4096, L, self.args.exp.sample_rate, device)     # only its residual_seed helper is used
         return self._stft
+
+    def evaluate(self, x, t, y, specY, filter_params, blind, lane=None):
+        if self.xi > 0 or y is None:
+            return super().evaluate(x, t, y, specY, filter_params, blind, lane)
+        # xi = 0: x0 = D(x) (no high-pass in this branch of the reference, :126), x0 <- y + x0 - A(x0), d = (x - x0) / t
+        from ..stft import fir_same
+        x_den = self.get_denoised_estimate(x, t, lane, hpf=False)
+        x0 = lincomb(torch.empty_like(x), 1.0, x_den, 1.0, y, -1.0, fir_same(x_den, self.fir_taps))
+        return lincomb(torch.empty_like(x), 1.0 / float(t), x, -1.0 / float(t), x0), x_den, filter_params
 
     def predict_bwe(self, ylpf, filt, filt_type):
         if filt_type not in ("firwin", "firwin_hpf"):

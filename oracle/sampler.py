@@ -124,11 +124,29 @@ class OracleEDMSampler:
     """Known-FIR-degradation sampler: /root/reference/testing/edm_sampler.py Sampler.predict :166-229,
     get_score_rec_guidance :56-94, apply_FIR_filter :245-252 (conv1d padding='same', no kernel flip)."""
 
-    def __init__(self, net, cqt, edm_params, *, audio_len, T=35, order=2, xi=0.25, filter_out_cqt_DC_Nyq=True):
+    def __init__(self, net, cqt, edm_params, *, audio_len, T=35, order=2, xi=0.25, filter_out_cqt_DC_Nyq=True,
+                 data_consistency=False):
         self.net, self.cqt, self.p = net, cqt, edm_params
         self.audio_len, self.T, self.order, self.xi, self.hpf = audio_len, T, order, xi, filter_out_cqt_DC_Nyq
+        self.data_consistency = data_consistency          # posterior_sampling.data_consistency (edm_sampler.py:47-54, :113-130)
 
     def score(self, x, t, y, taps):
+        fir = lambda v: torch.nn.functional.conv1d(v.unsqueeze(1), taps.view(1, 1, -1), padding="same").squeeze(1)
+        if self.xi <= 0:
+            # :124-130 - no guidance: the denoised estimate with the replacement step, always
+            with torch.no_grad():
+                xd = E.denoiser(self.p, self.net, x, t.reshape(1, 1).expand(x.shape[0], 1))   # (no hpf here in the reference)
+                xd = y + xd - fir(xd)
+                return (xd - x) / t ** 2
+        sc = self._guided(x, t, y, taps)
+        if self.data_consistency:
+            # :113-122 - Tweedie estimate, replacement x0 <- y + x0 - A(x0), back to a score
+            x0 = sc * t ** 2 + x
+            x0 = y + x0 - fir(x0)
+            sc = (x0 - x) / t ** 2
+        return sc
+
+    def _guided(self, x, t, y, taps):
         x = x.detach().requires_grad_(True)
         xd = E.denoiser(self.p, self.net, x, t.reshape(1, 1).expand(x.shape[0], 1))
         if self.hpf:

@@ -1036,8 +1036,46 @@ def g21():
          seed=2121, noise_seed=2100, res_a=0.3, start_sigma=0.05, mu=np.array([100.0, 1.0]), L=L, OLA=256,
          test_fc=2500.0, test_A=-35.0)
 
+# ---------------------------------------------------------------- G22: edm_sampler with the replacement step / without guidance
+def g22():
+    """testing/edm_sampler.py Sampler.predict_bwe('firwin') in its two other modes (get_score :96-132): (a)
+    posterior_sampling.data_consistency = True - guided score, then the replacement x0 <- y + x0 - A(x0) on the Tweedie estimate
+    (:113-122); (b) xi = 0 - no guidance, the replacement step on the plain denoised estimate (:124-130).  Same network,
+    observation and noise as G9 (edm_sampler_firwin.npz), T = 3."""
+    import yaml
+    esm = importlib.import_module("testing.edm_sampler")
+    ube = importlib.import_module("utils.bandwidth_extension")
+    out = {}
+    for key, dc, xi in (("dc", True, 0.25), ("xi0", False, 0.0)):
+        args = small_args(T=3)
+        with open(f"{ref_shim.REF}/conf/tester/edm_DC_correction_4s.yaml") as f:
+            args.tester = ref_shim.to_attr(yaml.safe_load(f))
+        args.tester.T = 3
+        args.tester.posterior_sampling.data_consistency = dc
+        args.tester.posterior_sampling.xi = xi
+        args.inference = ref_shim.to_attr(dict(mode="bandwidth_extension"))     # (:116 reads it; anything but phase_retrieval)
+        net, sd = build_ref_net(args)
+        with quiet():
+            s = esm.Sampler(ResidualNetRef(net, 0.3, 0.063), edm_mod.EDM(args), args)
+        L = args.exp.audio_len
+        g = torch.Generator().manual_seed(5151)
+        clean = 0.1 * torch.randn(1, L, generator=g)
+        taps = ube.get_FIR_lowpass(500, 1000, 1, 22050)
+        y = ube.apply_low_pass_firwin(clean, taps)
+        noises = [torch.randn(1, L, generator=g) for _ in range(1 + args.tester.T)]
+        it = iter(noises)
+        orig = torch.randn
+        torch.randn = lambda *a, **k: next(it)
+        try:
+            with quiet(), contextlib.redirect_stderr(io.StringIO()):
+                xr = s.predict_bwe(y.clone(), taps, "firwin")
+        finally:
+            torch.randn = orig
+        out[f"x_{key}"] = xr
+    save("edm_sampler_modes.npz", seed=5151, res_a=0.3, **out)
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
     for w in which:
         globals()[w]()

@@ -162,6 +162,32 @@ def test_edm_sampler_firwin_T3_vs_reference_golden():
     x = smp.predict_bwe(s["y"].cuda(), s["taps_22050"], "firwin")
     assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 2e-3
 
+@pytest.mark.parametrize("mode", ["dc", "xi0"])
+def test_edm_sampler_replacement_modes_T3_vs_reference_golden(mode):
+    """testing/edm_sampler.py with posterior_sampling.data_consistency = True (guided score, then x0 <- y + x0 - A(x0) on the
+    Tweedie estimate, :113-122) and with xi = 0 (the replacement step on the plain denoised estimate, :124-130) on the HIP path
+    vs the reference's outputs (tests/golden/make_golden.py::g22)."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.edm_sampler import Sampler
+    s9, s = load("edm_sampler_firwin.npz"), load("edm_sampler_modes.npz")
+    g, args, net = small_net(T=3)
+    args.tester.posterior_sampling.xi = float(s9["xi"]) if mode == "dc" else 0.0
+    args.tester.posterior_sampling.data_consistency = mode == "dc"
+    args.tester.diff_params.ro = float(s9["ro"])
+    args.tester.diff_params.sigma_max = float(s9["sigma_max"])
+    args.tester.diff_params.Schurn = float(s9["Schurn"])
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    smp = Sampler(ResidualNet(net, float(s["res_a"]), 0.063), EDM(args), args)
+    it = iter(noises)
+    smp._randn = lambda shape, device: next(it).to(device)
+    x = smp.predict_bwe(s9["y"].cuda(), s9["taps_22050"], "firwin")
+    ref = s[f"x_{mode}"]
+    print(f"edm_sampler {mode}: RMS err {rms_err(x, ref):.2e}, rel {rel(x, ref):.2e}")
+    assert rms_err(x, ref) < 1e-3 and rel(x, ref) < 2e-3
+
 
 @pytest.mark.parametrize("precision,tol_y,tol_g", [("bf16x3", 1e-4, 1e-3), ("bf16", 2e-2, 6e-2)])
 def test_unet_reduced_precision_modes_vs_reference_golden(precision, tol_y, tol_g):

@@ -94,6 +94,24 @@ def test_edm_sampler_firwin_T3():
     x = smp.predict_bwe(s["y"], s["taps_22050"], noises)
     assert rel(x, s["x"]) < 1e-3
 
+@pytest.mark.parametrize("mode", ["dc", "xi0"])
+def test_edm_sampler_replacement_modes_T3(mode):
+    """edm_sampler.Sampler in its two other modes (G22, /root/reference/testing/edm_sampler.py:96-132): guided score +
+    replacement step (posterior_sampling.data_consistency), and xi = 0 (replacement step on the plain denoised estimate)."""
+    from oracle.sampler import OracleEDMSampler
+    g, sd, cqt = small_net()
+    s9, s = load("edm_sampler_firwin.npz"), load("edm_sampler_modes.npz")
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    a = float(s["res_a"])
+    p = E.EDMParams(0.063, 1e-4, float(s9["sigma_max"]), float(s9["ro"]), Schurn=float(s9["Schurn"]), Stmin=0, Stmax=50, Snoise=1.0)
+    net = lambda x, cn: a * UN.unet_forward(sd, CFG, cqt, x, cn) + (torch.exp(4 * cn) / 0.063) * x
+    smp = OracleEDMSampler(net, cqt, p, audio_len=L, T=3, xi=float(s9["xi"]) if mode == "dc" else 0.0, data_consistency=mode == "dc")
+    x = smp.predict_bwe(s9["y"], s9["taps_22050"], noises)
+    assert rel(x, s[f"x_{mode}"]) < 1e-3
+
 
 def test_fir_taps_and_apply():
     import scipy.signal
