@@ -987,8 +987,10 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
         sW = sW < sWend ? sW : sWend;
     };
     f32x4* const Ww = Wb + wave * WWV;                   // this wave's part of ring position 0
+    // (ablation bits of this kernel, profiling builds only - results are wrong: 0x2000 no weight DMA, 0x4000 no row / edge / halo
+    // loads, 0x8000 no transform (halo permutes, vector work, LDS stores), 0x10000 no barrier)
 #define X_DMA(rp, j) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(Ww + (rp) * WSL + (j) * 64), 16, wvl[j], sW, 0, 0);
+    if (!(ABL & 0x2000)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(Ww + (rp) * WSL + (j) * 64), 16, wvl[j], sW, 0, 0);
 #define X_FENCE0 __builtin_amdgcn_sched_barrier(0);
 #if (ABL & 256)
 #define X_WAITVM(n) asm volatile("s_waitcnt vmcnt(0)");
@@ -1004,6 +1006,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
     int pS = 0;
     xve[0] = xve[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto issue_rows = [&](int ci0, int r0, int r1) __attribute__((always_inline)) {
+        if (ABL & 0x4000) return;
         const int so = (ci0 + 2 * wave) * cs1 * 4;
 #pragma unroll
         for (int r = 1; r < 5; ++r) {
@@ -1012,6 +1015,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
         }
     };
     auto issue_halo = [&](int ci0) __attribute__((always_inline)) {
+        if (ABL & 0x4000) return;
         const int so = (ci0 + 2 * wave) * cs1 * 4;
         xhl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ehalo, so, 0));
     };
@@ -1022,6 +1026,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
         }
     };
     auto issue_edge = [&](int ps, int ci0) __attribute__((always_inline)) {
+        if (ABL & 0x4000) return;
         const int so = (ci0 + 2 * wave) * cs1 * 4;
         const unsigned edge = ps == 2 ? 0u : OOBH;
         xve[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[0] | edge, so, 0));
@@ -1052,12 +1057,14 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
     // statement that consumes them waits).  Rows 0 / 5 are used by pass 2 only; their two bpermutes are issued in every pass
     // (an LDS instruction does not cost matrix-pipe time, a branch here would cost hipcc's register shuffling)
     auto halo_permute = [&]() __attribute__((always_inline)) {
+        if (ABL & 0x8000) return;
 #pragma unroll
         for (int r = 0; r < 6; ++r)
             asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(xh[r]) : "v"(hsrc), "v"(xhl), "n"(32 * r));
     };
     // (same arithmetic, in the same order, as conv_wino45_kernel::store_act: bit-identical products)
     auto store_act = [&](f32x4* buf) __attribute__((always_inline)) {
+        if (ABL & 0x8000) return;
         const int ps = pS;
         const f32x4 xv[6] = {xve[0], xvm[0], xvm[1], xvm[2], xvm[3], xve[1]};
         const float k2 = fsel(ps, 0x40800000u, 0x3f800000u, 0x40a00000u);
@@ -1231,7 +1238,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
             X_FENCE
             if constexpr (LATE) { X_WAITVM(13) } else { X_WAITVM(6) }
             asm volatile("s_waitcnt lgkmcnt(0)");
-            __builtin_amdgcn_s_barrier();
+            if (!(ABL & 0x10000)) __builtin_amdgcn_s_barrier();
             X_FENCE
             X_READ(0, Xw, 0, 0)
             if constexpr (!LATE) halo_permute();
@@ -1336,6 +1343,14 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
 #endif
 }
 
+// (Round 4 also built a THIRD generation - the weights not through LDS at all: wave w is the only consumer of its tile's weights
+// and its A fragment of a slot is exactly three coalesced 16-byte loads per lane, so the A operands were loaded global ->
+// registers into a ring, LDS holding X only.  With hipcc's own waitcnt insertion the ring got vmcnt(0) / vmcnt(1) in front of
+// the transform (write-after-write and branch-merge conservatism): slower (96-channel layers 678 vs 575 us).  With every loop
+// load as inline assembly and hand-counted waits, a 4-slot ring spilled inside the loop and a 2-slot ring was 2 % faster than
+// this kernel at best: the 10 % the weight DMA costs - ablation, same box: DMA off -10 %, row loads + transform off -22 %, barrier
+// off 0 %, all off -25 % = the MFMA + operand-read floor - is the ISSUE of its vector-memory instructions, not its LDS traffic,
+// and their number per MFMA is fixed by the tile: 128 B of weights per MFMA.  Removed again.)
 // dst [3 passes][CinP][CoutP][12]: pass ps holds frequency phases (1,2), (3,4), (0,5); entry 6*fpl + tp
 __global__ void pack_wino45_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int tf, int CinP,
                                    int CoutP, long total) {

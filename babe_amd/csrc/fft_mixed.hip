@@ -146,16 +146,40 @@ __global__ __launch_bounds__(FNT) void colfft_kernel(ColFFTArgs a) {
     if (tile >= a.tiles) return;                            // surplus tiles of the padding (whole workgroup)
     const int col0 = tile * FC;
     const int N = a.N;
-    for (int i = threadIdx.x; i < N; i += FNT) wl[i] = a.wN[i];
-    // ---- load: rows x 8 columns (c fastest: 32-byte segments per plane)
+    // (the table's loads are issued first and stored after the tile's first loads have been issued: one DRAM latency, not two)
+    float2 wreg[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int i = threadIdx.x + u * FNT;
+        wreg[u] = i < N ? a.wN[i] : make_float2(0.f, 0.f);
+    }
+    // ---- load: rows x 8 columns (c fastest: 32-byte segments per plane).  Four items per thread and round: the four (eight)
+    // global loads are issued back to back before their LDS stores - a one-item loop body serialises a DRAM latency per item
+    // (10 per thread at N = 644: measured 15 us per workgroup for 41 KB)
     {
         const float* re = a.in_re + (long)b * a.in_bs;
         const float* im = a.in_im ? a.in_im + (long)b * a.in_bs : nullptr;
-        for (int item = threadIdx.x; item < N * FC; item += FNT) {
-            const int c = item & (FC - 1), r = item >> 3;
-            const bool ok = r < a.in_rows && col0 + c < a.ncols;
-            const long o = (long)r * a.in_ld + col0 + c;
-            buf0[r * FCP + c] = make_float2(ok ? re[o] : 0.f, (ok && im) ? im[o] : 0.f);
+        for (int base = threadIdx.x; base < N * FC; base += 4 * FNT) {
+            float vr[4], vi[4];
+            if (base == (int)threadIdx.x) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (threadIdx.x + u * FNT < N) wl[threadIdx.x + u * FNT] = wreg[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int item = base + u * FNT;
+                const int c = item & (FC - 1), r = item >> 3;
+                const bool ok = item < N * FC && r < a.in_rows && col0 + c < a.ncols;
+                const long o = ok ? (long)r * a.in_ld + col0 + c : 0;
+                vr[u] = ok ? re[o] : 0.f;
+                vi[u] = (ok && im) ? im[o] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int item = base + u * FNT;
+                if (item < N * FC) buf0[(item >> 3) * FCP + (item & (FC - 1))] = make_float2(vr[u], vi[u]);
+            }
         }
     }
     __syncthreads();
@@ -183,17 +207,32 @@ __global__ __launch_bounds__(FNT) void colfft_kernel(ColFFTArgs a) {
     float* ore = a.out_re + (long)b * a.out_bs;
     float* oim = a.out_im ? a.out_im + (long)b * a.out_bs : nullptr;
     if (a.out_transposed) {
-        // out[col][row]: rows fastest across the threads (contiguous runs of N floats per column and plane)
-        for (int c = 0; c < FC; ++c) {
-            if (col0 + c >= a.ncols) break;
-            for (int r = threadIdx.x; r < N; r += FNT) {
-                float2 v = src[r * FCP + c];
+        // out[col][row]: rows fastest across the threads (contiguous runs of N floats per column and plane); ONE index space
+        // item = c N + r over the tile, four items per thread and round, their twiddle loads issued together (a loop over the
+        // 8 columns paid a DRAM latency per column)
+        const float inv_n = 1.f / (float)N;
+        for (int base = threadIdx.x; base < N * FC; base += 4 * FNT) {
+            float2 tw[4];
+            int rr[4], cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int item = base + u * FNT;
+                cc[u] = (int)(((float)item + 0.5f) * inv_n);
+                rr[u] = item - cc[u] * N;
+                tw[u] = make_float2(1.f, 0.f);
+                if (a.big_tw && item < N * FC && col0 + cc[u] < a.ncols)
+                    tw[u] = a.tw_mode == 1 ? a.big_tw[(long)rr[u] * a.tw_ld + col0 + cc[u]] : a.big_tw[(long)(col0 + cc[u]) * a.tw_ld + rr[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int item = base + u * FNT;
+                if (item >= N * FC || col0 + cc[u] >= a.ncols) continue;
+                float2 v = src[rr[u] * FCP + cc[u]];
                 if (a.big_tw) {
-                    float2 tw = a.tw_mode == 1 ? a.big_tw[(long)r * a.tw_ld + col0 + c] : a.big_tw[(long)(col0 + c) * a.tw_ld + r];
-                    if (INV) tw.y = -tw.y;
-                    v = cmul(v, tw);
+                    if (INV) tw[u].y = -tw[u].y;
+                    v = cmul(v, tw[u]);
                 }
-                const long o = (long)(col0 + c) * a.out_ld + r;
+                const long o = (long)(col0 + cc[u]) * a.out_ld + rr[u];
                 ore[o] = v.x;
                 if (oim) oim[o] = v.y;
             }
