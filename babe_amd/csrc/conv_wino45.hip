@@ -899,7 +899,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino45w_kernel(babe_conv_args a, 
 //   g0: D E E R R | g1: D R R | g2: D H | g3 .. g11: D          (D weight DMA chunk, E edge row, R row, H halo: 19 operations)
 // the DMAs of group 3i + j move chunk j of weight slot 4S + i + 3 into ring position (i + 3) & 3.  Operand reads of a new
 // slot are issued in the last group of the previous one: slot 1 at g2 (its last chunk was issued at g8 of the previous
-// super-slab: 13 younger operations), slot 2 at g5 (g11 of the previous one: 13), slot 3 at g8 (g2: 7), slot 0 of the next
+// super-slab: 11 younger operations without the edge rows), slot 2 at g5 (g11 of the previous one: 11), slot 3 at g8 (g2: 7), slot 0 of the next
 // super-slab at g11 (g5: 6).
 // (-DBABE_W45X_NUM_VGPR=96 caps the kernel at 192 registers - the attribute counts halves of the unified file - so that two
 // 64-register waves of the other lane's element-wise kernels would fit beside the two conv waves of a SIMD.  Measured, round 4,
@@ -999,6 +999,11 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
 #else
 #define X_WAITVM(n) asm volatile("s_waitcnt vmcnt(" #n ")");
 #endif
+#if (ABL & 0x20000)
+#define X_WAITVM13 X_WAITVM(13)
+#else
+#define X_WAITVM13 X_WAITVM(11)
+#endif
 
     f32x4 xvm[4], xve[2];
     float xhl = 0.f, xsc = 1.f;
@@ -1028,9 +1033,19 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
     auto issue_edge = [&](int ps, int ci0) __attribute__((always_inline)) {
         if (ABL & 0x4000) return;
         const int so = (ci0 + 2 * wave) * cs1 * 4;
+#if !(ABL & 0x20000)
+        // the two edge-row loads only in the pass that uses them (a wave-uniform branch; the hand-counted waits assume they are
+        // absent: 11 where the always-issued form - ABL bit 0x20000 - has 13).  A vector-memory instruction costs this kernel
+        // 1-2 % of its time whether it moves data or not (ablations): +2 % over all layers, +5 % on the 96-channel ones.
+        if (ps == 2) {
+            xve[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[0], so, 0));
+            xve[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[5], so, 0));
+        }
+#else
         const unsigned edge = ps == 2 ? 0u : OOBH;
         xve[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[0] | edge, so, 0));
         xve[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[5] | edge, so, 0));
+#endif
     };
     auto dpp_shr1 = [](float old, float src) __attribute__((always_inline)) {
         asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
@@ -1189,7 +1204,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
     }                                                                                                           \
     if constexpr ((j) == 2) {                                                                                   \
         w_next();                                                                                               \
-        if constexpr (((g) < 6) != LATE) { X_WAITVM(13) } else { X_WAITVM(6) }                                  \
+        if constexpr (((g) < 6) != LATE) { X_WAITVM13 } else { X_WAITVM(6) }                                    \
     }                                                                                                           \
     X_READ(cr, Xs, sl, pgr)                                                                                     \
     X_FENCE                                                                                                     \
@@ -1236,7 +1251,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
             X_DMA(2, 2)
             w_next();
             X_FENCE
-            if constexpr (LATE) { X_WAITVM(13) } else { X_WAITVM(6) }
+            if constexpr (LATE) { X_WAITVM13 } else { X_WAITVM(6) }
             asm volatile("s_waitcnt lgkmcnt(0)");
             if (!(ABL & 0x10000)) __builtin_amdgcn_s_barrier();
             X_FENCE
@@ -1303,6 +1318,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
 #undef X_DMA
 #undef X_FENCE0
 #undef X_WAITVM
+#undef X_WAITVM13
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");          // (the tail's clamped loads / out-of-range DMAs: nothing may land after the exit)
 
     // ---- output (as conv_wino45w_kernel)
