@@ -1179,6 +1179,9 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
         acc[0][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][0][i], acc[0][4 * (pg) + i], 0, 0, 0); \
         if (two) acc[1][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][1][i], acc[1][4 * (pg) + i], 0, 0, 0); \
     }
+#define X_MFMA1(c, pg, i)                                                                            \
+    acc[0][4 * (pg) + (i)] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][0][i], acc[0][4 * (pg) + (i)], 0, 0, 0); \
+    if (two) acc[1][4 * (pg) + (i)] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][1][i], acc[1][4 * (pg) + (i)], 0, 0, 0);
 #define X_READ(c, Xp, sl, pg)                                       \
     av[c] = Ww[(sl) * WSL + aoff + (pg)];                           \
     bv[c][0] = (Xp)[boff + (sl) * KQ * NU * 3 + (pg)];              \
@@ -1206,8 +1209,10 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
         w_next();                                                                                               \
         if constexpr (((g) < 6) != LATE) { X_WAITVM13 } else { X_WAITVM(6) }                                    \
     }                                                                                                           \
-    X_READ(cr, Xs, sl, pgr)                                                                                     \
-    X_FENCE                                                                                                     \
+    if constexpr (!SPREAD || (g) == SA) {                                                                       \
+        X_READ(cr, Xs, sl, pgr)                                                                                 \
+        X_FENCE                                                                                                 \
+    }                                                                                                           \
     if constexpr ((g) == SA) {                                                                                  \
         /* transform of super-slab S + 1 (rows loaded one super-slab ago), then the loads of super-slab S + 2 */ \
         store_act(Xw);                                                                                          \
@@ -1223,11 +1228,30 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
         halo_permute();                                                                                         \
         X_FENCE                                                                                                 \
     }                                                                                                           \
-    X_MFMA(cm, pgm)                                                                                             \
+    if constexpr (!SPREAD || (g) == SA) {                                                                       \
+        X_MFMA(cm, pgm)                                                                                         \
+    } else {                                                                                                    \
+        /* the three operand reads of group g + 1 one at a time BETWEEN the MFMA pairs of group g (tools/mfma_feed.hip: the */ \
+        /* bare loop runs at 0.991 of the peak this way, 0.969 with the reads clustered in front of the eight MFMAs) */ \
+        X_MFMA1(cm, pgm, 0)                                                                                     \
+        X_FENCE                                                                                                 \
+        av[cr] = Ww[(sl) * WSL + aoff + (pgr)];                                                                 \
+        X_FENCE                                                                                                 \
+        X_MFMA1(cm, pgm, 1)                                                                                     \
+        X_FENCE                                                                                                 \
+        bv[cr][0] = Xs[boff + (sl) * KQ * NU * 3 + (pgr)];                                                      \
+        X_FENCE                                                                                                 \
+        X_MFMA1(cm, pgm, 2)                                                                                     \
+        X_FENCE                                                                                                 \
+        if (two) bv[cr][1] = Xs[boff + (sl) * KQ * NU * 3 + 16 * 3 + (pgr)];                                    \
+        X_FENCE                                                                                                 \
+        X_MFMA1(cm, pgm, 3)                                                                                     \
+    }                                                                                                           \
     X_FENCE
     auto run = [&](auto late_c) __attribute__((always_inline)) {
         constexpr bool LATE = decltype(late_c)::value;
         constexpr int SA = LATE ? 6 : 0;
+        constexpr bool SPREAD = (ABL & 0x40000) != 0;
         X_READ(0, Xb, 0, 0)
         if constexpr (!LATE) halo_permute();              // (super-slab 1's halo: waits for its load)
         int cM = 0, pM = 0;
@@ -1313,6 +1337,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
 #endif
 #undef X_G
 #undef X_MFMA
+#undef X_MFMA1
 #undef X_READ
 #undef X_FENCE
 #undef X_DMA
