@@ -158,11 +158,11 @@ def cpu_baseline():
     return out
 
 
-PMC_TRAFFIC_FILE = "r03_conv_traffic.json"
+PMC_TRAFFIC_FILE = "r04_conv_traffic.json"
 
 
 def conv_traffic(precision):
-    """HBM-side bytes per launch of the dominant conv kernel (conv_wino45_kernel + conv_wino45w_kernel) from the committed PMC passes (rocprofv3 cannot run inside the bench; the
+    """HBM-side bytes per launch of the dominant conv kernel (conv_wino45x_kernel) from the committed PMC passes (rocprofv3 cannot run inside the bench; the
     passes are separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this command, profiles/README.md)."""
     path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     if precision != "f32" or not os.path.exists(path):
@@ -372,7 +372,7 @@ def main():
             tr = conv_traffic(a.precision)
             roof = {
                 "bound": "mfma",
-                "kernel": (("conv_wino45_kernel / conv_wino45w_kernel (64- / 128-channel tiles of the same algorithm; one "
+                "kernel": (("conv_wino45x_kernel / conv_wino45_kernel (128- / 96- and 64-channel tiles of the same algorithm; one "
                             "measurement slot): nested Winograd F(2,5) along frequency x F(4,3) along time, fp32 "
                             "v_mfma_f32_16x16x4_f32 (executes 0.3 of the algorithmic flops), fwd + input-VJP launches of every "
                             "(5,3) layer of the UNet with >= 64 channels (all_conv_kernels has the rest)" if dom == "conv53_wino45" else

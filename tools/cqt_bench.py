@@ -46,7 +46,8 @@ for B in [int(v) for v in os.environ.get("BS", "1,2,8,32,64").split(",")]:
     tb = lambda us: by / us / 1e6          # algorithmic bytes (5.63 MB per clip) / GPU time -> TB/s
     print(f"B={B:3d} [GPU time, HIP events] band_analysis {g_an:7.1f} us = {tb(g_an):5.2f} TB/s ({tb(g_an) / 8 * 100:4.1f}% of 8 TB/s) | "
           f"band_synthesis {g_sy:7.1f} us + gather {g_ga:6.1f} us = {tb(g_sy + g_ga):5.2f} TB/s ({tb(g_sy + g_ga) / 8 * 100:4.1f}%) "
-          f"[band_synthesis alone {tb(g_sy):5.2f} TB/s] | rfft_L: 2 DFT stages {g_dft:6.1f} us each + twiddle_transpose {g_tt:6.1f} us")
+          f"[band_synthesis alone {tb(g_sy):5.2f} TB/s] | rfft_L: " +
+          (f"mixed-radix, 2 launches {g_tt:6.1f} us" if getattr(cq.fft, "mixed", False) else f"2 dense DFT stages {g_dft:6.1f} us each + twiddle_transpose {g_tt:6.1f} us"))
     t_fftT = timeit(lambda: cq.fft.rfft_T(spec))
     print(f"B={B:3d} [Python loop, wall]    analysis {t_an*1e3:8.1f} us | synthesis(+gather) {t_sy*1e3:8.1f} us | rfft_L {t_fft*1e3:8.1f} us | rfft_L^T {t_fftT*1e3:8.1f} us  (mixed-radix: {getattr(cq.fft, 'mixed', False)})")
     # whole transforms (what the UNet calls): fwd = rfft_L + band analysis; algorithmic bytes = signal in + coefficients out

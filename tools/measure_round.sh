@@ -1,25 +1,31 @@
 #!/bin/bash
-# Round measurement suite (run on the GPU box through gpurun): writes everything under gpurun_out/$1/
-# usage: tools/measure_round.sh r3m
+# Round measurement suite (run on the GPU box through gpurun): writes everything under gpurun_out/$1/ with prefix $2 (e.g. r04)
+# usage: tools/measure_round.sh r4m r04
 set -x
 out=gpurun_out/$1
+pre=${2:-r04}
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 python3 -m pytest tests -m gpu -q -s > $out/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $out/gpu_tests.log
-python3 bench.py --steps 5 --warmup 2 > $out/bench.json 2> $out/bench.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2> $out/bench.err
 python3 tools/conv_shapes_bench.py > $out/conv_shapes_fwd.txt 2>&1
-echo "---- BABE_CONV_WINO45=0 (conv_wino4p on every (5,3) layer), same box" >> $out/conv_shapes_fwd.txt
-BABE_CONV_WINO45=0 python3 tools/conv_shapes_bench.py >> $out/conv_shapes_fwd.txt 2>&1
+echo "---- BABE_CONV_WINO45X=0 (first-generation wide kernel conv_wino45w), same box" >> $out/conv_shapes_fwd.txt
+BABE_CONV_WINO45X=0 python3 tools/conv_shapes_bench.py >> $out/conv_shapes_fwd.txt 2>&1
+VJP=1 python3 tools/conv_shapes_bench.py > $out/conv_shapes_vjp.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/trace_bench.json 2> $out/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --T 2 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $out/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --T 2 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $out/pmc_write.err
-python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/r03 conv_wino45
+python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/$pre conv_wino45x
 SHAPES=enc3.H0,enc5.H0,enc6.H0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $out/pmc_sq -- python3 tools/conv_shapes_bench.py > /dev/null 2>&1
-python3 tools/pmc_summary.py $out/pmc_sq conv_wino45 > $out/pmc_wino45.txt
+python3 tools/pmc_summary.py $out/pmc_sq conv_wino45 > $out/pmc_wino45x.txt
 SHAPES=enc3.H0,enc5.H0,enc6.H0 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA --output-format csv -d $out/pmc_insts -- python3 tools/conv_shapes_bench.py > /dev/null 2>&1
-python3 tools/pmc_summary.py $out/pmc_insts conv_wino45 >> $out/pmc_wino45.txt
+python3 tools/pmc_summary.py $out/pmc_insts conv_wino45 >> $out/pmc_wino45x.txt
+python3 tools/cqt_bench.py > $out/cqt_bench.txt 2>&1
+python3 tools/filter_fit_bench.py > $out/filter_fit.txt 2>&1
+./tools/bin/mfma_feed > $out/mfma_feed.txt 2>&1
+python3 tools/host_enqueue_time.py > $out/host_enqueue_time.txt 2>&1
 # keep the small summaries only
 find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 rm -rf $out/trace $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/pmc_insts
 ls -la $out
-tail -c 600 $out/bench.json
+tail -c 400 $out/bench_driver_cmd.json
