@@ -105,3 +105,29 @@ def test_hip_vs_cqt_nsgt_pytorch_library(pair):
         assert rel(got, torch.from_numpy(z[f"{tag}.fwd{j}"])) < 1e-4, f"fwd octave {j}"
     assert rel(hip.bwd_planar(co)[:, ::sub], torch.from_numpy(z[f"{tag}.bwd"])) < 1e-4
     assert rel(hip.apply_hpf_DC(x)[:, ::sub], torch.from_numpy(z[f"{tag}.hpf"])) < 1e-4
+
+
+@pytest.mark.parametrize("L", [46046, 184184, 92092, 368368, 441000])
+def test_length_L_fft_and_transpose_other_lengths(L):
+    """The mixed-radix four-step FFT (csrc/fft_mixed.hip) picks its radices per length - 46046 = (2 7 13)(11 23), 184184 = (4 7 13)
+    (2 11 23): config #5's segment, ... - and 441000 has a factor the Stockham kernel cannot split into at most six of its radices
+    per stage... or can: either way RealFFT must equal torch.fft.rfft and its transpose must be the adjoint."""
+    from babe_amd.cqt import RealFFT
+    try:
+        fft = RealFFT(L, torch.device("cuda"))
+    except ValueError:
+        pytest.skip(f"L={L}: no balanced factorisation (unsupported length, as before)")
+    g = torch.Generator().manual_seed(L % 997)
+    x = torch.randn(2, L, generator=g)
+    spec = fft.rfft(x.cuda())
+    ref = torch.fft.rfft(x.double())
+    got = torch.complex(spec[:, 0, : L // 2 + 1].double().cpu(), spec[:, 1, : L // 2 + 1].double().cpu())
+    err = float((got - ref).abs().max() / ref.abs().max())
+    G = torch.zeros(2, 2, fft.KX)
+    G[:, :, : L // 2 + 1] = torch.randn(2, 2, L // 2 + 1, generator=g)
+    xt = fft.rfft_T(G.cuda())
+    lhs = float((spec.double().cpu() * G.double()).sum())
+    rhs = float((x.double() * xt.double().cpu()).sum())
+    print(f"L={L}: N1 x N2 = {fft.N1} x {fft.N2}, mixed-radix {fft.mixed} ({getattr(fft, 'rad1', None)} / {getattr(fft, 'rad2', None)}), rfft err {err:.1e}")
+    assert err < 5e-6
+    assert abs(lhs - rhs) < 2e-5 * (abs(lhs) + abs(rhs) + 1e3)
