@@ -157,6 +157,7 @@ class RealFFT:
     """Length-L real DFT / its transpose on the GPU (four-step, dense DFT stages on the MFMA conv kernel)."""
 
     def __init__(self, L, device):
+        _register_sigs()                     # (a RealFFT used on its own: ctypes must know the pointer arguments are 64-bit)
         self.L = L
         N1, N2 = factor_len(L)
         self.N1, self.N2 = N1, N2
