@@ -84,42 +84,77 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     const float* x = in + (long)b * in_bs + (long)c * in_cs + (long)f * Tin;
     float* y = out + (long)b * out_bs + (long)c * out_cs + (long)f * Tout + n0;
     float s[V];
-    bool fast = false;
     if constexpr (V == 4) {
-        // interior fast paths: the 4 outputs share one register window of the source row (14 or 6 loads instead of 32 /
-        // 16); same tap order as resample_one, so the results are identical
+        // The 4 outputs share one register window of the source row.  Interior threads read it with 16- / 8-byte loads;
+        // the first and last thread of a row build the same window element by element - reflected (modes 0, 1: the forward
+        // resamplers pad by reflection) or zero-padded (modes 2, 3: the adjoints see a gradient that ends) - and add the few
+        // taps the reflection folds back onto the first / last samples.  Same tap order as resample_one (V = 1 path), so
+        // the results are identical; the deep UNet levels (T = 64, 128: 2 of 16 / 32 threads of every row are border threads,
+        // i.e. every wave has some) no longer run the generic per-output loops beside the fast path (mode 2 at T = 128:
+        // 1.6 TB/s, round 3).
         if (mode == 0 || mode == 3) {                       // y[n] = sum_k h[k] src[2n - 3 + k]
-            const bool inner = mode == 0 ? (2 * n0 - 3 >= 0 && 2 * n0 + 10 <= T - 1) : (n0 >= 3 && n0 + 3 <= T - 4);
+            float w[14];
+            const int base = 2 * n0 - 3;
+            const bool inner = base >= 0 && base + 13 <= Tin - 1;
             if (inner) {
-                float w[14];
-                if (VI && 2 * n0 - 4 >= 0 && 2 * n0 + 11 <= Tin - 1) {
+                if (VI && base - 1 >= 0 && base + 14 <= Tin - 1) {
                     typedef float f32x4 __attribute__((ext_vector_type(4)));
-                    const f32x4* p4 = reinterpret_cast<const f32x4*>(x + 2 * n0 - 4);      // n0 % 4 == 0: 16-byte aligned
+                    const f32x4* p4 = reinterpret_cast<const f32x4*>(x + base - 1);        // n0 % 4 == 0: 16-byte aligned
                     const f32x4 q0 = p4[0], q1 = p4[1], q2 = p4[2], q3 = p4[3];
                     const float X[16] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3],
                                          q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
 #pragma unroll
                     for (int j = 0; j < 14; ++j) w[j] = X[j + 1];
                 } else {
-                    const float* p = x + 2 * n0 - 3;
 #pragma unroll
-                    for (int j = 0; j < 14; ++j) w[j] = p[j];
+                    for (int j = 0; j < 14; ++j) w[j] = x[base + j];
                 }
+            } else {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) a += kH[k] * w[2 * v + k];
-                    s[v] = alpha * a;
+                for (int j = 0; j < 14; ++j) {
+                    const int idx = base + j;
+                    w[j] = mode == 0 ? x[refl(idx, T)] : ((idx >= 0 && idx < Tin) ? x[idx] : 0.f);
                 }
-                fast = true;
             }
+            float raw[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += kH[k] * w[2 * v + k];
+                raw[v] = acc;
+            }
+            if (mode == 3) {
+                // n = 1, 2: + up_gpad(2 - n);  n = T-3, T-2: + up_gpad(2T - n)   (w[j] = gy[2 n0 - 3 + j])
+                if (n0 == 0) {
+                    float e = 0.f;
+                    e += kH[5] * w[3];
+                    e += kH[6] * w[4];
+                    e += kH[7] * w[5];
+                    raw[1] += e;
+                    float e2 = 0.f;
+                    e2 += kH[7] * w[3];
+                    raw[2] += e2;
+                }
+                if (n0 == T - 4) {
+                    float e = 0.f;
+                    e += kH[0] * w[10];
+                    raw[1] += e;
+                    float e2 = 0.f;
+                    e2 += kH[0] * w[8];
+                    e2 += kH[1] * w[9];
+                    e2 += kH[2] * w[10];
+                    raw[2] += e2;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) s[v] = alpha * raw[v];
         } else {                                            // 4-tap polyphase: even n taps (1,3,5,7), odd n taps (0,2,4,6)
             const int m = n0 >> 1;
             const int len = mode == 1 ? T : T / 2;          // source row length
-            const bool inner = m - 2 >= 0 && m + 3 <= len - 1 && (mode == 1 || (n0 >= 4 && n0 + 3 <= T - 5));
+            const bool inner = m - 2 >= 0 && m + 3 <= len - 1;
+            float w[6];
             if (inner) {
-                float w[6];
                 if (VI) {
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
                     const f32x2* p2 = reinterpret_cast<const f32x2*>(x + m - 2);           // m even: 8-byte aligned
@@ -129,15 +164,49 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 #pragma unroll
                     for (int j = 0; j < 6; ++j) w[j] = x[m - 2 + j];     // w[j] = src[m - 2 + j]
                 }
-                s[0] = alpha * (kH[1] * w[3] + kH[3] * w[2] + kH[5] * w[1] + kH[7] * w[0]);
-                s[1] = alpha * (kH[0] * w[4] + kH[2] * w[3] + kH[4] * w[2] + kH[6] * w[1]);
-                s[2] = alpha * (kH[1] * w[4] + kH[3] * w[3] + kH[5] * w[2] + kH[7] * w[1]);
-                s[3] = alpha * (kH[0] * w[5] + kH[2] * w[4] + kH[4] * w[3] + kH[6] * w[2]);
-                fast = true;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int idx = m - 2 + j;
+                    w[j] = mode == 1 ? x[refl(idx, T)] : ((idx >= 0 && idx < len) ? x[idx] : 0.f);
+                }
             }
+            float raw[4];
+            raw[0] = kH[1] * w[3] + kH[3] * w[2] + kH[5] * w[1] + kH[7] * w[0];
+            raw[1] = kH[0] * w[4] + kH[2] * w[3] + kH[4] * w[2] + kH[6] * w[1];
+            raw[2] = kH[1] * w[4] + kH[3] * w[3] + kH[5] * w[2] + kH[7] * w[1];
+            raw[3] = kH[0] * w[5] + kH[2] * w[4] + kH[4] * w[3] + kH[6] * w[2];
+            if (mode == 2) {
+                // n = 1, 2, 3: + down_gpad(3 - n);  n = T-4 .. T-2: + down_gpad(2T + 1 - n)   (w[j] = gy[m - 2 + j])
+                if (n0 == 0) {
+                    float e = 0.f;
+                    e += kH[0] * w[3];
+                    e += kH[2] * w[2];
+                    raw[1] += e;                             // gpad[2] = h0 gy[1] + h2 gy[0]
+                    float e2 = 0.f;
+                    e2 += kH[1] * w[2];
+                    raw[2] += e2;                            // gpad[1] = h1 gy[0]
+                    float e3 = 0.f;
+                    e3 += kH[0] * w[2];
+                    raw[3] += e3;                            // gpad[0] = h0 gy[0]
+                }
+                if (n0 == T - 4) {
+                    float e = 0.f;
+                    e += kH[7] * w[3];
+                    raw[0] += e;                             // gpad[T+5] = h7 gy[Th-1]
+                    float e2 = 0.f;
+                    e2 += kH[6] * w[3];
+                    raw[1] += e2;                            // gpad[T+4] = h6 gy[Th-1]
+                    float e3 = 0.f;
+                    e3 += kH[5] * w[3];
+                    e3 += kH[7] * w[2];
+                    raw[2] += e3;                            // gpad[T+3] = h5 gy[Th-1] + h7 gy[Th-2]
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) s[v] = alpha * raw[v];
         }
-    }
-    if (!fast) {
+    } else {
 #pragma unroll
         for (int v = 0; v < V; ++v) s[v] = alpha * resample_one(x, n0 + v, T, mode);
     }
