@@ -57,10 +57,19 @@ __device__ __forceinline__ void block_reduce2(double& s0, double& s1, double* sh
     }
 }
 
-// grid: (S, B*G)
+// grid: (S, B*G).  FUSED: the workgroup that finishes a (b, g) group LAST also does gn_finalize's work for it (same reduction
+// order over the S partial sums, so the statistics are bit-identical to the two-launch form): one launch per GroupNorm instead
+// of two.  "Last" = the S-th arrival at a per-group ticket (atomic add after a device-scope fence); the last workgroup resets the
+// ticket to 0, so the buffer needs zeroing once, when it is allocated (one buffer per stream: babe_amd/ops.py).
+template <bool FUSED>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
-                                                         long n, int S) {
+                                                         long n, int S, int* __restrict__ ticket,
+                                                         const float* __restrict__ gamma, const float* __restrict__ film,
+                                                         long film_bs, float* __restrict__ stats, float* __restrict__ scale,
+                                                         int C, int G, float eps) {
     __shared__ double sh[8];
+    __shared__ int last_sh;
+    __shared__ float r_sh;
     const int s = blockIdx.x;
     const long bg = blockIdx.y;
     const long chunk = ((n / 4 + S - 1) / S) * 4;       // multiple of 4 elements
@@ -99,6 +108,49 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     if (threadIdx.x == 0) {
         part[(bg * S + s) * 2] = s0;
         part[(bg * S + s) * 2 + 1] = s1;
+    }
+    if constexpr (FUSED) {
+        if (threadIdx.x == 0) {
+            __threadfence();                                   // the partial sums above are visible device-wide before the ticket
+            const int old = atomicAdd(&ticket[bg], 1);
+            last_sh = old == S - 1;
+            if (old == S - 1) ticket[bg] = 0;                  // every workgroup of this group has arrived: ready for the next call
+        }
+        __syncthreads();
+        if (!last_sh) return;
+        __threadfence();
+        // gn_finalize_kernel's arithmetic for this one group: lanes 0-31 add the S partial sums (lane s, s + 32, ...), xor-shuffle
+        const int b = (int)(bg / G), g = (int)(bg % G);
+        if (threadIdx.x < 32) {
+            const volatile double* vp = part;                  // written by other workgroups of THIS launch: not through a stale L1 line
+            double t0 = 0, t1 = 0;
+            for (int q = threadIdx.x; q < S; q += 32) {
+                t0 += vp[(bg * S + q) * 2];
+                t1 += vp[(bg * S + q) * 2 + 1];
+            }
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) {
+                t0 += __shfl_xor(t0, o, 32);
+                t1 += __shfl_xor(t1, o, 32);
+            }
+            if (threadIdx.x == 0) {
+                const double mean = t0 / (double)n;
+                double var = (t1 - (double)n * mean * mean) / (double)(n - 1);
+                if (var < 0) var = 0;
+                const float sd = (float)sqrt(var);
+                const float r = 1.f / (sd + eps);
+                stats[(b * G + g) * 3 + 0] = (float)mean;
+                stats[(b * G + g) * 3 + 1] = sd;
+                stats[(b * G + g) * 3 + 2] = r;
+                r_sh = r;
+            }
+        }
+        __syncthreads();
+        const int cg = C / G;
+        for (int j = threadIdx.x; j < cg; j += blockDim.x) {
+            const int c = g * cg + j;
+            scale[b * C + c] = gamma[c] * (film[(long)b * film_bs + c] + 1.f) * r_sh;
+        }
     }
 }
 
@@ -319,7 +371,21 @@ extern "C" int babe_gn_partial(const float* x, double* part, int B, int G, long 
     BABE_CHECK_ARG(x && part && B > 0 && G > 0 && n > 1 && S > 0, "gn_partial: bad arguments");
     BABE_CHECK_ARG(n % 4 == 0, "gn_partial: group size %ld not a multiple of 4", n);
     BabeProfScope prof(BABE_SLOT_GN_STATS, 4.0 * B * G * (double)n, 0, 0, stream);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(S, B * G), dim3(256), 0, (hipStream_t)stream, x, part, n, S);
+    hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(S, B * G), dim3(256), 0, (hipStream_t)stream, x, part, n, S,
+                       (int*)nullptr, (const float*)nullptr, (const float*)nullptr, 0L, (float*)nullptr, (float*)nullptr, 0, 1, 0.f);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+/* babe_gn_partial + babe_gn_finalize in ONE launch (same results bit for bit).  ticket: B*G ints, zero when first used and left
+ * zero by every call; calls that may run concurrently (different streams) need different ticket buffers. */
+extern "C" int babe_gn_stats(const float* x, double* part, int* ticket, const float* gamma, const float* film, long film_bs,
+                             float* stats, float* scale, int B, int C, int G, long n, int S, float eps, void* stream) {
+    BABE_CHECK_ARG(x && part && ticket && gamma && film && stats && scale && B > 0 && G > 0 && n > 1 && S > 0, "gn_stats: bad arguments");
+    BABE_CHECK_ARG(n % 4 == 0 && G <= 64 && C % G == 0, "gn_stats: n=%ld C=%d G=%d unsupported", n, C, G);
+    BabeProfScope prof(BABE_SLOT_GN_STATS, 4.0 * B * G * (double)n, 0, 0, stream);
+    hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(S, B * G), dim3(256), 0, (hipStream_t)stream, x, part, n, S, ticket, gamma,
+                       film, film_bs, stats, scale, C, G, eps);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

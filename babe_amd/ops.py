@@ -156,8 +156,30 @@ def _splits(n, B, G):
     return int(s)
 
 
+_GN_TICKETS = {}
+# Measured (round 4, same box, A/B/A/B): the one-launch form is SLOWER on the whole job - 1.992 / 1.991 vs 2.080 / 2.079 audio-sec/s -
+# every workgroup of a 10 us streaming kernel pays a device-scope fence + an atomic before it retires, and the last one a
+# serial tail; the separate 3.5 us finalize launch overlaps the other lane's kernels instead.  Off by default (BABE_GN_FUSED=1).
+GN_FUSED = os.environ.get("BABE_GN_FUSED", "0") == "1"
+
+
+def _gn_ticket(dev, n):
+    """Zero-initialised ticket buffer of the fused statistics kernel, one per (device, current stream): calls on different
+    streams may run concurrently and must not share tickets; every call leaves its tickets at zero."""
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    t = _GN_TICKETS.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(n, 1024), device=dev, dtype=torch.int32)
+        _GN_TICKETS[key] = t
+        from ._lib import bump_alloc_generation
+        bump_alloc_generation()
+    return t
+
+
 def gn_scale(x, gamma, film, G=8, eps=1e-7):
-    """Returns (stats [B,G,3], scale [B,C]) with scale = gamma*(film+1)/(std+eps).  x dense [B,C,F,T]."""
+    """Returns (stats [B,G,3], scale [B,C]) with scale = gamma*(film+1)/(std+eps).  x dense [B,C,F,T].
+    Two launches (partial sums, finalize); BABE_GN_FUSED=1 = one launch (csrc/norm.hip gn_partial_kernel<true>: the last
+    workgroup of a group finalises it; bit-identical, measured slower on the whole job - see GN_FUSED above)."""
     assert x.is_contiguous()
     B, Cc, F, T = x.shape
     n = (Cc // G) * F * T
@@ -166,8 +188,12 @@ def gn_scale(x, gamma, film, G=8, eps=1e-7):
     stats = torch.empty(B, G, 3, device=x.device, dtype=torch.float32)
     scale = torch.empty(B, Cc, device=x.device, dtype=torch.float32)
     L = lib()
-    check(L.babe_gn_partial(ptr(x), ptr(part), B, G, n, S, stream()), "gn_partial")
     assert film.stride(1) == 1
+    if GN_FUSED:
+        check(L.babe_gn_stats(ptr(x), ptr(part), ptr(_gn_ticket(x.device, B * G)), ptr(gamma), ptr(film), film.stride(0),
+                              ptr(stats), ptr(scale), B, Cc, G, n, S, eps, stream()), "gn_stats")
+        return stats, scale
+    check(L.babe_gn_partial(ptr(x), ptr(part), B, G, n, S, stream()), "gn_partial")
     check(L.babe_gn_finalize(ptr(part), ptr(gamma), ptr(film), film.stride(0), ptr(stats), ptr(scale), B, Cc, G, n, S,
                              eps, stream()), "gn_finalize")
     return stats, scale

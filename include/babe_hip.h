@@ -120,6 +120,10 @@ int babe_prof_dispatch_counts(long* counts, int reset);
 /* ---- BiasFreeGroupNorm + FiLM + GELU: cqtdiff+.py:147-163, :472-482 ------------------------ */
 /* partial sums (double) of x and x^2 per (b,group,split): part[(b*G+g)*S+s] = {sum, sumsq} */
 int babe_gn_partial(const float* x, double* part, int B, int G, long n_per_group, int S, void* stream);
+/* babe_gn_partial + babe_gn_finalize in one launch (the workgroup that finishes a group last finalises it; bit-identical
+ * results).  ticket: B*G ints, zero before the first use and left zero by every call; one buffer per concurrently used stream. */
+int babe_gn_stats(const float* x, double* part, int* ticket, const float* gamma, const float* film, long film_bs,
+                  float* stats, float* scale, int B, int C, int G, long n_per_group, int S, float eps, void* stream);
 /* stats[b*G+g] = {mean, std, 1/(std+eps)}; scale[b][c] = gamma[c]*(film[b][c]+1)/(std+eps) */
 int babe_gn_finalize(const double* part, const float* gamma, const float* film, long film_bs,
                      float* stats, float* scale, int B, int C, int G, long n_per_group, int S,

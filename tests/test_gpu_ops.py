@@ -269,6 +269,38 @@ def test_groupnorm_film_gelu_fwd_bwd(ops, B, C, Fq, T):
     ops.gn_bwd(xc, dac, gx, scale, stats, gx, 0.5)
     assert rel(gx, gref) < 5e-6
 
+def test_gn_stats_one_launch_equals_two_launches(ops):
+    """gn_partial_kernel<true> (the last workgroup of a group finalises it: one launch) against babe_gn_partial +
+    babe_gn_finalize: bit-identical statistics and scales, over shapes with different split counts on the SAME ticket buffer
+    (every call must leave its tickets at zero), and from two streams at once."""
+    g = torch.Generator().manual_seed(77)
+    shapes = [(2, 64, 16, 256), (1, 96, 24, 64), (2, 128, 40, 128), (1, 256, 56, 64), (2, 64, 16, 256)]
+    for rep in range(2):
+        for (B, C, F, T) in shapes:
+            x = torch.randn(B, C, F, T, generator=g).cuda()
+            gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+            film = torch.randn(B, C, generator=g).cuda()
+            ops.GN_FUSED = True
+            st1, sc1 = ops.gn_scale(x, gamma, film)
+            ops.GN_FUSED = False
+            st0, sc0 = ops.gn_scale(x, gamma, film)
+            ops.GN_FUSED = True
+            assert torch.equal(st1, st0) and torch.equal(sc1, sc0), (B, C, F, T)
+    assert all(int(t.abs().sum()) == 0 for t in ops._GN_TICKETS.values())
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.randn(2, 128, 64, 256, generator=g).cuda()
+    gamma, film = torch.ones(128, device="cuda"), torch.zeros(2, 128, device="cuda")
+    ref = ops.gn_scale(x, gamma, film)
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(8):
+        with torch.cuda.stream(sA):
+            outs.append(ops.gn_scale(x, gamma, film))
+        with torch.cuda.stream(sB):
+            outs.append(ops.gn_scale(x, gamma, film))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) for o in outs)
+
 
 @pytest.mark.parametrize("T", [16, 22, 64, 600])
 def test_resample_fwd_and_adjoint(ops, T):
