@@ -51,6 +51,7 @@ _SIGS = {
     "babe_conv_pack_weights_wino45": [_P, _P, _I, _I, _I, _I, _I, _P],
     "babe_conv_pack_weights_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "babe_gn_partial": [_P, _P, _I, _I, _L, _I, _P],
+    "babe_scale_gelu_fin": [_P, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _L, _I, _F, _P],
     "babe_gn_stats": [_P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _L, _I, _F, _P],
     "babe_gn_finalize": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _L, _I, _F, _P],
     "babe_scale_gelu": [_P, _P, _P, _I, _I, _L, _P],

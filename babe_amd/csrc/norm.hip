@@ -212,6 +212,65 @@ __global__ __launch_bounds__(256) void scale_gelu_kernel(const float* __restrict
         for (long i = nv * 4 + threadIdx.x; i < hw; i += blockDim.x) a[base + i] = gelu_f(x[base + i] * sc);
 }
 
+// scale_gelu with gn_finalize's work folded into its prologue (one launch less on every layer's critical path): each workgroup
+// re-derives 1/(std + eps) of its channel's group from the S partial sums - the same reduction order as gn_finalize_kernel, so
+// the scale is bit-identical - and the first workgroup of a channel also stores scale[b][c] (and the group's statistics) for the
+// VJP.  No atomics, no fences: the partial sums come from the previous launch on the stream.
+__global__ __launch_bounds__(256) void scale_gelu_fin_kernel(const float* __restrict__ x, const double* __restrict__ part,
+                                                             const float* __restrict__ gamma, const float* __restrict__ film,
+                                                             long film_bs, float* __restrict__ stats, float* __restrict__ scale,
+                                                             float* __restrict__ a, int C, int G, long hw, long n, int S,
+                                                             float eps) {
+    __shared__ float sc_sh;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int cg = C / G, g = c / cg;
+    if (threadIdx.x < 32) {
+        double t0 = 0, t1 = 0;
+        for (int q = threadIdx.x; q < S; q += 32) {
+            t0 += part[((long)(b * G + g) * S + q) * 2];
+            t1 += part[((long)(b * G + g) * S + q) * 2 + 1];
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            t0 += __shfl_xor(t0, o, 32);
+            t1 += __shfl_xor(t1, o, 32);
+        }
+        if (threadIdx.x == 0) {
+            const double mean = t0 / (double)n;
+            double var = (t1 - (double)n * mean * mean) / (double)(n - 1);
+            if (var < 0) var = 0;
+            const float sd = (float)sqrt(var);
+            const float r = 1.f / (sd + eps);
+            const float scv = gamma[c] * (film[(long)b * film_bs + c] + 1.f) * r;
+            sc_sh = scv;
+            if (blockIdx.x == 0) {
+                scale[b * C + c] = scv;
+                if (c == g * cg) {
+                    stats[(b * G + g) * 3 + 0] = (float)mean;
+                    stats[(b * G + g) * 3 + 1] = sd;
+                    stats[(b * G + g) * 3 + 2] = r;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float sc = sc_sh;
+    const long base = ((long)b * C + c) * hw;
+    const long nv = hw / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    float4* a4 = reinterpret_cast<float4*>(a + base);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        float4 v = x4[i];
+        v.x = gelu_f(v.x * sc);
+        v.y = gelu_f(v.y * sc);
+        v.z = gelu_f(v.z * sc);
+        v.w = gelu_f(v.w * sc);
+        a4[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (long i = nv * 4 + threadIdx.x; i < hw; i += blockDim.x) a[base + i] = gelu_f(x[base + i] * sc);
+}
+
 // scale*GELU written as bf16 "units" for the pipelined bf16 conv (conv_bf16p.hip, UNITS variant): a unit = 8 consecutive
 // channels of one (f, t) as 8 bf16 = 16 bytes - exactly one lane's MFMA B-operand fragment.  Layout
 // [B][C/8][F][4 planes][T/4 + 1] units, plane p entry j = time step 4j + p - 1 (so a conv tile's operand runs S(m) are
@@ -409,6 +468,24 @@ extern "C" int babe_scale_gelu(const float* x, const float* scale, float* a, int
     if (bx < 1) bx = 1;
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(scale_gelu_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, scale, a, C, hw);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+/* babe_gn_finalize + babe_scale_gelu in one launch: part from babe_gn_partial (same B, G, n, S); writes a = gelu(x * scale) and,
+ * for the VJP, stats [B][G][3] and scale [B][C] - bit-identical to the two separate calls. */
+extern "C" int babe_scale_gelu_fin(const float* x, const double* part, const float* gamma, const float* film, long film_bs,
+                                   float* stats, float* scale, float* a, int B, int C, int G, long hw, int S, float eps,
+                                   void* stream) {
+    BABE_CHECK_ARG(x && part && gamma && film && stats && scale && a && B > 0 && C > 0 && hw > 0 && S > 0, "scale_gelu_fin: bad arguments");
+    BABE_CHECK_ARG(hw % 4 == 0 && G <= 64 && C % G == 0, "scale_gelu_fin: hw=%ld C=%d G=%d unsupported", hw, C, G);
+    BabeProfScope prof(BABE_SLOT_SCALE_GELU, 8.0 * B * C * (double)hw, 0, 0, stream);
+    int bx = cdiv(hw / 4, 256 * 4);
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    const long n = (long)(C / G) * hw;
+    hipLaunchKernelGGL(scale_gelu_fin_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, part, gamma, film, film_bs,
+                       stats, scale, a, C, G, hw, n, S, eps);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

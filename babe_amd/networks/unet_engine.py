@@ -150,16 +150,16 @@ class UnetEngine:
             au = self.scratch_i16("au", B * ops.lib().babe_units_size(N, Fq, T) * 8)
         for d in range(blk.nd):
             aoff, goff = blk.film_off[d]
-            stats, scale = ops.gn_scale(z, blk.gamma[d], self._film(film, aoff, N))
             gate = self._film(film, goff, N).contiguous()
             znew = self.buf(B, N, Fq, T)
             ua = ops.units_args(au, blk.H[d], znew, N, dil=blk.dil(d), res=z, oscale=gate, alpha=RS2, rbeta=RS2) if units else None
             if ua is not None and ops.units_supported(ua):       # the library's verdict, not a Python guess
+                stats, scale = ops.gn_scale(z, blk.gamma[d], self._film(film, aoff, N))
                 ops.scale_gelu_units(z, scale, au)
                 ops.conv2d_units(au, blk.H[d], znew, N, args=ua)
             else:
                 a = self.scratch("a", B * N * Fq * T).view(B, N, Fq, T)
-                ops.scale_gelu(z, scale, a)
+                stats, scale = ops.gn_scale_gelu(z, blk.gamma[d], self._film(film, aoff, N), a)     # (finalize inside the GELU launch)
                 ops.conv2d(a, blk.H[d], znew, dil=blk.dil(d), res=z, oscale=gate, alpha=RS2, rbeta=RS2)
             saved.append((z, stats, scale, gate))
             z = znew

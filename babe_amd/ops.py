@@ -199,6 +199,30 @@ def gn_scale(x, gamma, film, G=8, eps=1e-7):
     return stats, scale
 
 
+GELU_FIN = os.environ.get("BABE_GELU_FIN", "1") != "0"
+
+
+def gn_scale_gelu(x, gamma, film, out, G=8, eps=1e-7):
+    """gn_scale + scale_gelu with the finalize folded into the GELU kernel's prologue: out = gelu(x * scale); returns
+    (stats [B,G,3], scale [B,C]) for the VJP.  Bit-identical to gn_scale followed by scale_gelu (BABE_GELU_FIN=0)."""
+    if not GELU_FIN:
+        stats, scale = gn_scale(x, gamma, film, G, eps)
+        scale_gelu(x, scale, out)
+        return stats, scale
+    assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape and film.stride(1) == 1
+    B, Cc, F, T = x.shape
+    n = (Cc // G) * F * T
+    S = _splits(n, B, G)
+    part = torch.empty(B * G * S * 2, device=x.device, dtype=torch.float64)
+    stats = torch.empty(B, G, 3, device=x.device, dtype=torch.float32)
+    scale = torch.empty(B, Cc, device=x.device, dtype=torch.float32)
+    L = lib()
+    check(L.babe_gn_partial(ptr(x), ptr(part), B, G, n, S, stream()), "gn_partial")
+    check(L.babe_scale_gelu_fin(ptr(x), ptr(part), ptr(gamma), ptr(film), film.stride(0), ptr(stats), ptr(scale), ptr(out),
+                                B, Cc, G, F * T, S, eps, stream()), "scale_gelu_fin")
+    return stats, scale
+
+
 def scale_gelu(x, scale, out):
     B, Cc, F, T = x.shape
     assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape

@@ -128,6 +128,10 @@ int babe_gn_stats(const float* x, double* part, int* ticket, const float* gamma,
 int babe_gn_finalize(const double* part, const float* gamma, const float* film, long film_bs,
                      float* stats, float* scale, int B, int C, int G, long n_per_group, int S,
                      float eps, void* stream);
+/* babe_gn_finalize + babe_scale_gelu in one launch (every workgroup re-derives its channel's scale from the partial sums in
+ * gn_finalize's order; the first one stores scale / stats for the VJP): bit-identical to the two calls. */
+int babe_scale_gelu_fin(const float* x, const double* part, const float* gamma, const float* film, long film_bs, float* stats,
+                        float* scale, float* a, int B, int C, int G, long hw, int S, float eps, void* stream);
 /* a = gelu(x * scale[b][c]) */
 int babe_scale_gelu(const float* x, const float* scale, float* a, int B, int C, long hw, void* stream);
 /* VJP pass 1: with du = da * gelu'(x*scale) (never stored): part[(b*G+g)*S+s] = sum(du * scale*(std+eps) * x) */

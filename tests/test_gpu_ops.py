@@ -301,6 +301,21 @@ def test_gn_stats_one_launch_equals_two_launches(ops):
     torch.cuda.synchronize()
     assert all(torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) for o in outs)
 
+def test_scale_gelu_with_folded_finalize_is_bit_identical(ops):
+    """babe_scale_gelu_fin (gn_finalize's work in the GELU kernel's prologue) against gn_scale + scale_gelu."""
+    g = torch.Generator().manual_seed(78)
+    for (B, C, F, T) in [(2, 64, 16, 256), (1, 96, 24, 64), (2, 128, 40, 128), (1, 256, 56, 64)]:
+        x = torch.randn(B, C, F, T, generator=g).cuda()
+        gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+        film = torch.randn(B, C, generator=g).cuda()
+        st0, sc0 = ops.gn_scale(x, gamma, film)
+        a0 = ops.scale_gelu(x, sc0, torch.empty_like(x))
+        a1 = torch.empty_like(x)
+        keep, ops.GELU_FIN = ops.GELU_FIN, True
+        st1, sc1 = ops.gn_scale_gelu(x, gamma, film, a1)
+        ops.GELU_FIN = keep
+        assert torch.equal(st1, st0) and torch.equal(sc1, sc0) and torch.equal(a1, a0), (B, C, F, T)
+
 
 @pytest.mark.parametrize("T", [16, 22, 64, 600])
 def test_resample_fwd_and_adjoint(ops, T):
