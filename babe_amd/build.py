@@ -30,9 +30,21 @@ COMMON_FLAGS = ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "
 EXTRA_FLAGS = {}
 
 
+def _compile_cmd(src):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o",
+            os.path.join(HERE, "build", src + ".o"), "-Wno-unused-result"] + COMMON_FLAGS + EXTRA_FLAGS.get(src, [])
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
+    for src in SOURCES:                                # flags changed since the objects were built?
+        stamp = os.path.join(HERE, "build", src + ".o.cmd")
+        if os.path.isdir(os.path.join(HERE, "build")) and os.path.exists(os.path.join(HERE, "build", src + ".o")):
+            cmd = " ".join(_compile_cmd(src))
+            if not os.path.exists(stamp) or open(stamp).read() != cmd:
+                return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "babe_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
@@ -59,6 +71,7 @@ def _build_locked(force, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    stamps = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     hdr_mtime = max([os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h")] +
                     [os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "babe_hip.h"))])
@@ -68,11 +81,15 @@ def _build_locked(force, verbose):
             raise FileNotFoundError(f"{p}: listed in babe_amd/build.py SOURCES but missing")
         o = os.path.join(HERE, "build", src + ".o")
         objs.append(o)
-        # every object depends on its source, on every header in csrc/ and on the public header
-        if (not force) and os.path.exists(o) and os.path.getmtime(o) > max([os.path.getmtime(p), hdr_mtime]):
+        cmd = _compile_cmd(src)
+        # every object depends on its source, on every header in csrc/, on the public header AND on its compile command (the
+        # flags are a correctness contract - no packed-fp32 instructions -: an object built under other flags is rebuilt)
+        stamp = o + ".cmd"
+        cmd_txt = " ".join(cmd)
+        same_cmd = os.path.exists(stamp) and open(stamp).read() == cmd_txt
+        if (not force) and same_cmd and os.path.exists(o) and os.path.getmtime(o) > max([os.path.getmtime(p), hdr_mtime]):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", p, "-o", o,
-               "-Wno-unused-result"] + COMMON_FLAGS + EXTRA_FLAGS.get(src, [])
+        stamps.append((stamp, cmd_txt))
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -88,6 +105,9 @@ def _build_locked(force, verbose):
                 print(out)
     if failed:
         raise RuntimeError("hipcc failed")
+    for stamp, txt in stamps:
+        with open(stamp, "w") as fh:
+            fh.write(txt)
     tmp = OUT + f".tmp{os.getpid()}"
     # -z defs: an undefined symbol (e.g. a kernel stub the host pass silently dropped) fails the link, not the first call
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", tmp] + objs

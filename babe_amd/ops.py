@@ -93,12 +93,16 @@ class PackedConv:
             self.bwd_wino4 = torch.empty(L.babe_conv_packed_size_wino4(self.Cout, self.Cin, self.KH, 1), device=w.device)
             check(L.babe_conv_pack_weights_wino4(ptr(w), ptr(self.fwd_wino4), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack_wino4")
             check(L.babe_conv_pack_weights_wino4(ptr(w), ptr(self.bwd_wino4), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino4")
+        # nested-Winograd images (36 floats per weight pair and direction): only for the direction(s) the kernel can take -
+        # babe_conv2d_wino45_supported needs the EXECUTED op's input channels % 16 == 0 and more than 32 output channels
         self.fwd_wino45 = self.bwd_wino45 = None
-        if self.KH == 5 and self.KW == 3 and WINOGRAD45 and min(self.Cout, self.Cin) > 32:
-            self.fwd_wino45 = torch.empty(L.babe_conv_packed_size_wino45(self.Cout, self.Cin, 0), device=w.device)
-            self.bwd_wino45 = torch.empty(L.babe_conv_packed_size_wino45(self.Cout, self.Cin, 1), device=w.device)
-            check(L.babe_conv_pack_weights_wino45(ptr(w), ptr(self.fwd_wino45), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack_wino45")
-            check(L.babe_conv_pack_weights_wino45(ptr(w), ptr(self.bwd_wino45), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino45")
+        if self.KH == 5 and self.KW == 3 and WINOGRAD45:
+            if self.Cin % 16 == 0 and self.Cout > 32:
+                self.fwd_wino45 = torch.empty(L.babe_conv_packed_size_wino45(self.Cout, self.Cin, 0), device=w.device)
+                check(L.babe_conv_pack_weights_wino45(ptr(w), ptr(self.fwd_wino45), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack_wino45")
+            if self.Cout % 16 == 0 and self.Cin > 32:
+                self.bwd_wino45 = torch.empty(L.babe_conv_packed_size_wino45(self.Cout, self.Cin, 1), device=w.device)
+                check(L.babe_conv_pack_weights_wino45(ptr(w), ptr(self.bwd_wino45), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino45")
 
 
 def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=None, oscale=None, alpha=1.0, rbeta=0.0,
@@ -139,7 +143,7 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
         check(lib().babe_conv2d_bf16(C.byref(a), ptr(wq), pc.splits, stream()), "conv2d_bf16")
     elif FEWCO and getattr(pc, "w_raw", None) is not None and Cout <= 4 and lib().babe_conv2d_fewco_supported(C.byref(a)):
         check(lib().babe_conv2d_fewco(C.byref(a), ptr(pc.w_raw), int(transpose), stream()), "conv2d_fewco")
-    elif getattr(pc, "fwd_wino45", None) is not None and (lib().babe_conv2d_wino45_supported(C.byref(a)) if force_nested
+    elif getattr(pc, "bwd_wino45" if transpose else "fwd_wino45", None) is not None and (lib().babe_conv2d_wino45_supported(C.byref(a)) if force_nested
                                                           else lib().babe_conv2d_wino45_preferred(C.byref(a))):
         check(lib().babe_conv2d_wino45(C.byref(a), ptr(pc.bwd_wino45 if transpose else pc.fwd_wino45), stream()), "conv2d_wino45")
     elif getattr(pc, "fwd_wino4", None) is not None and lib().babe_conv2d_wino4_supported(C.byref(a)):
