@@ -992,7 +992,9 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
 #define X_DMA(rp, j) \
     if (!(ABL & 0x2000)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(Ww + (rp) * WSL + (j) * 64), 16, wvl[j], sW, 0, 0);
 #define X_FENCE0 __builtin_amdgcn_sched_barrier(0);
-#if (ABL & 256)
+#if (ABL & 0x100000)
+#define X_WAITVM(n)                                      /* (ablation: no counted waits at all - racy, timing only) */
+#elif (ABL & 256)
 #define X_WAITVM(n) asm volatile("s_waitcnt vmcnt(0)");
 #elif (ABL & 512)
 #define X_WAITVM(n) asm volatile("s_waitcnt vmcnt(0)"); __builtin_amdgcn_s_barrier();
@@ -1094,7 +1096,8 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
             float d[6];
 #pragma unroll
             for (int r = 1; r < 5; ++r)
-                d[r] = j == 0 ? dpp_shr1(xh[r], xv[r][3]) : (j == 5 ? dpp_shl1(xh[r], xv[r][0]) : xv[r][j - 1]);
+                d[r] = (ABL & 0x80000) ? xv[r][j == 0 ? 0 : (j == 5 ? 3 : j - 1)]
+                                        : (j == 0 ? dpp_shr1(xh[r], xv[r][3]) : (j == 5 ? dpp_shl1(xh[r], xv[r][0]) : xv[r][j - 1]));
             const float e = d[4] - k2 * d[2];
             const float o = k3 * d[3] - k1 * d[1];
             Ea[j] = za * o + e;
@@ -1117,8 +1120,16 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
             }
         }
         float Ua[6], Ub[6];
-        tt(Ea, Ua);
-        tt(Eb, Ub);
+        if (ABL & 0x80000) {                              // (ablation: no time transform, no halo assembly - what a producer-side
+#pragma unroll                                            //  time transform would leave in this kernel; results are wrong)
+            for (int j = 0; j < 6; ++j) {
+                Ua[j] = Ea[j];
+                Ub[j] = Eb[j];
+            }
+        } else {
+            tt(Ea, Ua);
+            tt(Eb, Ub);
+        }
         buf[xlds] = f32x4{Ua[0], Ua[1], Ua[2], Ua[3]};
         buf[xlds + 1] = f32x4{Ua[4], Ua[5], Ub[0], Ub[1]};
         buf[xlds + 2] = f32x4{Ub[2], Ub[3], Ub[4], Ub[5]};
