@@ -524,6 +524,43 @@ def test_graph_replay_equals_eager():
     assert torch.equal(other[0], want[0]) and torch.equal(other[1], want[1])
     assert not torch.equal(other[0], eager[0])
 
+def test_graphs_are_dropped_when_scratch_is_reallocated():
+    """A captured graph bakes raw pointers of the engine scratch it does not keep alive.  Shape A is captured; an eager call with
+    a LARGER batch then re-allocates the scratch (the old tensor is freed); shape A again must not replay the stale graphs
+    (babe_amd/_lib.alloc_generation: every (re)allocation of scratch / packed weights / tables bumps a generation the graph
+    cache is keyed on) - it runs eagerly, equals the first eager result bit for bit, and captures afresh on the next call."""
+    from babe_amd._lib import alloc_generation
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    g, args, net = small_net(T=3, start_sigma=0.05)
+    L = 92092
+    gen = torch.Generator().manual_seed(79)
+    yA, yB = 0.1 * torch.randn(2, L, generator=gen), 0.1 * torch.randn(6, L, generator=gen)
+    nA = [torch.randn(2, L, generator=gen) for _ in range(4)]
+    nB = [torch.randn(6, L, generator=gen) for _ in range(4)]
+
+    def run(smp, y, noises):
+        it = iter(noises)
+        smp._randn = lambda shape, device: next(it).to(device)
+        out = smp.predict_blind_bwe(y.cuda())
+        torch.cuda.synchronize()
+        return out
+
+    smp = BlindSampler(net, EDM(args), args, batch_semantics="per_clip")
+    smp.GRAPHS = True
+    eagerA = run(smp, yA, nA)
+    capA = run(smp, yA, nA)
+    assert any("graphs" in v for v in smp._graphs.values())
+    gen0 = alloc_generation()
+    run(smp, yB, nB)                                  # 3 segments per lane: larger scratch, larger saved activations
+    assert alloc_generation() > gen0, "the larger batch did not re-allocate anything: the test does not exercise the hazard"
+    againA = run(smp, yA, nA)                         # must NOT be a replay of the graphs captured above
+    assert all("graphs" not in v for v in smp._graphs.values()) or alloc_generation() == smp._graphs_gen
+    for o in (capA, againA):
+        assert torch.equal(o[0], eagerA[0]) and torch.equal(o[1], eagerA[1])
+    recap = run(smp, yA, nA)                          # and the configuration can be captured again
+    assert torch.equal(recap[0], eagerA[0])
+
 
 @pytest.mark.parametrize("norm", ["cosine", "smoothl1"])
 def test_blind_sampler_alternative_guidance_distances(norm):
