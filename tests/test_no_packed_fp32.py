@@ -1,6 +1,10 @@
-"""The HIP library must not contain packed-fp32 instructions (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32, v_pk_mov_b32):
-kernels that contain them return wrong sums when they run on a second stream beside the bf16 conv (DESIGN.md 8,
-babe_amd/build.py, profiles/r03_coresidency_probe.txt).  Disassembles the device code of the built library - no GPU needed."""
+"""The HIP library must not contain packed-fp32 instructions (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32, v_pk_mov_b32) nor any
+instruction with an op_sel modifier: on the MI355X pool `v_pk_{mul,add,fma}_f32 ... op_sel:[0,1]` (low result half reads the HIGH
+word of src1) computes as if that word were 0 while another kernel's waves run bf16 MFMA on the same CU - reduced in round 4 to
+the 60-line self-contained tools/pk_opsel_min.hip (profiles/r04_coresidency_repro.txt).  The library was affected
+in round 3 when hipcc's defaults put such instructions into conv_fewco / the CQT kernels; the build flags
+(babe_amd/build.py COMMON_FLAGS) remove them and this test keeps it that way.  Disassembles the device code of the built library
+- no GPU needed."""
 import glob
 import os
 import shutil
@@ -21,13 +25,15 @@ def test_library_has_no_packed_fp32_instructions(tmp_path):
     subprocess.run([OBJDUMP, "--offloading", str(local)], check=True, capture_output=True)     # extracts the code objects
     bundles = [p for p in glob.glob(str(local) + ".*") if "amdgcn" in p]
     assert bundles, "no device code objects found in the library"
-    packed, mfma = [], 0
+    packed, opsel, mfma = [], [], 0
     for b in bundles:
         asm = subprocess.run([OBJDUMP, "-d", b], check=True, capture_output=True, text=True).stdout
         mfma += asm.count("v_mfma_")
         packed += [l.strip() for l in asm.splitlines() if "v_pk_" in l and "_f32" in l or "v_pk_mov_b32" in l]
+        opsel += [l.strip() for l in asm.splitlines() if "op_sel" in l]
     assert mfma > 1000, "disassembly found no MFMA instructions: the check did not see the kernels"
     assert not packed, f"{len(packed)} packed-fp32 instructions in the library, e.g. {packed[:3]}"
+    assert not opsel, f"{len(opsel)} instructions with an op_sel modifier in the library, e.g. {opsel[:3]}"
 
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump not available")

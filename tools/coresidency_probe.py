@@ -19,7 +19,7 @@ def mkconv(prec, Cin, Cout, F, T, kh, dil, kind, B=2):
     ww = torch.randn(Cout, Cin, kh, kw, device="cuda") / math.sqrt(Cin * kh * kw); pc = ops.PackedConv(ww, prec)
     xx = torch.randn(B, Cin, F, T, device="cuda"); out = torch.empty(B, Cout, F, T, device="cuda")
     scale = torch.ones(B, Cin, device="cuda")
-    au = torch.empty(ops.lib().babe_units_size(Cin, F, T) * 8 * B, dtype=torch.int16, device="cuda") if kind == "units" else None
+    au = torch.empty(ops.lib().babe_units_size(Cin, F, T) * 8 * B, dtype=torch.int16, device="cuda") if kind in ("units", "sgu") else None
     def f():
         if kind == "units": ops.scale_gelu_units(xx, scale, au); ops.conv2d_units(au, pc, out, Cin, dil=dil)
         elif kind == "sgu": ops.scale_gelu_units(xx, scale, au if au is not None else None)
@@ -31,6 +31,7 @@ partners = {
     "bf16p fwd 256ch": mkconv("bf16", 256, 256, 448, 64, 5, 2, "fwd"),
     "bf16p vjp 256ch": mkconv("bf16", 256, 256, 448, 64, 5, 2, "vjp"),
     "bf16p units 64ch": mkconv("bf16", 64, 64, 64, 4096, 5, 1, "units"),
+    "sgu only 64ch": mkconv("bf16", 64, 64, 64, 4096, 5, 1, "sgu"),
     "bf16p fwd 64ch": mkconv("bf16", 64, 64, 64, 4096, 5, 1, "fwd"),
     "bf16p units 128ch": mkconv("bf16", 128, 128, 256, 512, 5, 4, "units"),
     "bf16p 1x1 512->256": mkconv("bf16", 512, 256, 448, 64, 1, 1, "fwd"),
@@ -41,6 +42,9 @@ partners = {
 sel = os.environ.get("PARTNERS")
 if sel:
     partners = {k: v for k, v in partners.items() if any(t in k for t in sel.split(","))}
+vsel = os.environ.get("VICTIMS")
+if vsel:
+    victims = {k: v for k, v in victims.items() if k in vsel.split(",")}
 sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
 for vn, vf in victims.items():
     ref = vf().clone(); torch.cuda.synchronize()

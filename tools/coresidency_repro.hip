@@ -53,20 +53,23 @@ int main(int argc, char** argv) {
     float *x, *w, *y, *yref;
     CK(hipMalloc(&x, hx.size() * 4)); CK(hipMalloc(&w, hw.size() * 4)); CK(hipMalloc(&y, (size_t)F * T * 4)); CK(hipMalloc(&yref, (size_t)F * T * 4));
     CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
-    // aggressor: babe_conv2d_bf16, 256 -> 256 channels, (5,3), dil 2, B = 2, F = 448, T = 64
-    const int AC = 256, AB = 2;
+    // aggressor: babe_conv2d_bf16, AC -> AC channels, (5,3), B = 2; default = the 64-channel layer of the UNet (64 x 4096, dil 1);
+    // argv: trials AC AF AT dil
+    const int AC = argc > 2 ? atoi(argv[2]) : 64, AB = 2, AF = argc > 3 ? atoi(argv[3]) : 64, AT = argc > 4 ? atoi(argv[4]) : 4096;
+    const int adil = argc > 5 ? atoi(argv[5]) : 1;
     float *ax, *aw, *ao; void* awp;
-    CK(hipMalloc(&ax, (size_t)AB * AC * F * T * 4)); CK(hipMalloc(&ao, (size_t)AB * AC * F * T * 4)); CK(hipMalloc(&aw, (size_t)AC * AC * 15 * 4));
-    CK(hipMemset(ax, 0x3c, (size_t)AB * AC * F * T * 4)); CK(hipMemset(aw, 0x3c, (size_t)AC * AC * 15 * 4));
+    const size_t an = (size_t)AB * AC * AF * AT;
+    CK(hipMalloc(&ax, an * 4)); CK(hipMalloc(&ao, an * 4)); CK(hipMalloc(&aw, (size_t)AC * AC * 15 * 4));
+    CK(hipMemset(ax, 0x3c, an * 4)); CK(hipMemset(aw, 0x3c, (size_t)AC * AC * 15 * 4));
     CK(hipMalloc(&awp, (size_t)babe_conv_packed_size_bf16(AC, AC, 5, 3, 0, 1) * 2));
     hipStream_t sA, sB;
     CK(hipStreamCreate(&sA)); CK(hipStreamCreate(&sB));
     if (babe_conv_pack_weights_bf16(aw, awp, AC, AC, 5, 3, 0, 1, sB)) { printf("pack: %s\n", babe_last_error()); return 2; }
     babe_conv_args a;
     memset(&a, 0, sizeof a);
-    a.in = ax; a.in_bs = (long)AC * F * T; a.in_cs = (long)F * T; a.cin_split = AC;
-    a.out = ao; a.out_bs = (long)AC * F * T; a.out_cs = (long)F * T; a.alpha = 1.f;
-    a.B = AB; a.Cin = AC; a.Cout = AC; a.F = F; a.T = T; a.KH = 5; a.KW = 3; a.dil = 2;
+    a.in = ax; a.in_bs = (long)AC * AF * AT; a.in_cs = (long)AF * AT; a.cin_split = AC;
+    a.out = ao; a.out_bs = (long)AC * AF * AT; a.out_cs = (long)AF * AT; a.alpha = 1.f;
+    a.B = AB; a.Cin = AC; a.Cout = AC; a.F = AF; a.T = AT; a.KH = 5; a.KW = 3; a.dil = adil;
     auto run_victim = [&](float* out, hipStream_t st) {
         hipLaunchKernelGGL(victim, dim3((F * T / 4 + 255) / 256), dim3(256), C * 5 * 16, st, x, w, out, C, F, T);
     };
@@ -86,7 +89,7 @@ int main(int argc, char** argv) {
             if (memcmp(&hy[k], &href[k], 4)) { ++nb; double d = fabs((double)hy[k] - href[k]); if (d > worst) worst = d; }
         bad_runs += nb > 0; bad_elems += nb;
     }
-    printf("victim beside babe_conv2d_bf16: %d of %d runs differ from the victim alone (%ld elements in total, worst |diff| %.3e)\n",
-           bad_runs, trials, bad_elems, worst);
+    printf("victim beside babe_conv2d_bf16 (%d ch, %d x %d, dil %d): %d of %d runs differ from the victim alone (%ld elements in total, worst |diff| %.3e)\n",
+           AC, AF, AT, adil, bad_runs, trials, bad_elems, worst);
     return 0;
 }

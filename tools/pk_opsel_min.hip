@@ -1,0 +1,61 @@
+// MINIMAL reproducer (self-contained, 60 lines) of the round-3 "co-residency" finding on MI355X (gfx950):
+//     v_pk_mul_f32 d, x, r op_sel:[0,1]     - low half of d = x.lo * r.HI -
+// computes its low half as if r.HI were 0 (d.lo = 0; v_pk_add_f32 gives x.lo + 0) in some lanes while waves of ANOTHER kernel
+// execute v_mfma_f32_16x16x32_bf16 on the same CU.  Alone, or beside v_mfma_f32_16x16x4_f32, it is always right.
+// The full matrix (other packed instructions / op_sel forms / MFMA shapes) is tools/pk_opsel_repro.hip.
+// Build + run: hipcc --offload-arch=gfx950 -O3 tools/pk_opsel_min.hip -o tools/bin/pk_opsel_min && tools/bin/pk_opsel_min
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void victim(unsigned* wrong, int iters) {
+    unsigned nb = 0;
+    const f32x2 x = {2.f, 4.f};
+    for (int it = 0; it < iters; ++it) {
+        const float a = (float)((threadIdx.x * 37 + it * 101 + blockIdx.x) % 1021 + 1), b = a + 1.f;
+        f32x2 r = {a, b}, d;
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=&v"(d) : "v"(x), "v"(r));
+        nb += (d[0] != 2.f * b) + (d[1] != 4.f * b);
+    }
+    if (nb) atomicAdd(wrong, nb);
+}
+
+template <bool BF16, bool UNIFORM_B = false>
+__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters) {
+    extern __shared__ float pad[];                 // 57 KB per workgroup: two workgroups per CU, room left for the victim
+    bf16x8 av, bv;
+    const int l = threadIdx.x;
+    for (int i = 0; i < 8; ++i) { av[i] = (__bf16)(0.01f * (l + i)); bv[i] = (__bf16)(UNIFORM_B ? 0.02f * i : 0.02f * (l - i)); }
+    f32x4 acc[4] = {};
+    for (int it = 0; it < iters; ++it)
+        for (int j = 0; j < 4; ++j)
+            acc[j] = BF16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[j], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_16x16x4f32(0.01f * threadIdx.x, 0.5f + j, acc[j], 0, 0, 0);
+    out[blockIdx.x * 256 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + (out == nullptr ? pad[0] : 0.f);
+}
+
+template <bool BF16, bool UB = false>
+unsigned run(unsigned* wrong, float* out, hipStream_t sA, hipStream_t sB, bool with_partner) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_loop<BF16, UB>), hipFuncAttributeMaxDynamicSharedMemorySize, 58368);
+    (void)hipMemset(wrong, 0, 4);
+    if (with_partner) hipLaunchKernelGGL((mfma_loop<BF16, UB>), dim3(4096), dim3(256), 58368, sB, out, 4000);
+    hipLaunchKernelGGL(victim, dim3(2048), dim3(256), 0, sA, wrong, 2000);
+    if (with_partner) hipLaunchKernelGGL((mfma_loop<BF16, UB>), dim3(4096), dim3(256), 58368, sB, out, 4000);
+    (void)hipDeviceSynchronize();
+    unsigned h = 0;
+    (void)hipMemcpy(&h, wrong, 4, hipMemcpyDeviceToHost);
+    return h;
+}
+
+int main() {
+    unsigned* wrong; float* out; hipStream_t sA, sB;
+    (void)hipMalloc(&wrong, 4); (void)hipMalloc(&out, 4096 * 256 * 4); (void)hipStreamCreate(&sA); (void)hipStreamCreate(&sB);
+    printf("v_pk_mul_f32 op_sel:[0,1], 2048 x 256 threads x 2000 products x 2 halves:\n");
+    printf("  alone                                   : %u wrong\n", run<true>(wrong, out, sA, sB, false));
+    for (int i = 0; i < 3; ++i) printf("  beside v_mfma_f32_16x16x4_f32  (stream B): %u wrong\n", run<false>(wrong, out, sA, sB, true));
+    for (int i = 0; i < 3; ++i) printf("  beside v_mfma_f32_16x16x32_bf16 (stream B): %u wrong\n", run<true>(wrong, out, sA, sB, true));
+    for (int i = 0; i < 3; ++i) printf("  beside v_mfma_f32_16x16x32_bf16, B operand the same in every lane: %u wrong\n", run<true, true>(wrong, out, sA, sB, true));
+    return 0;
+}

@@ -1,0 +1,128 @@
+// Self-contained reproducer (no library): on MI355X (gfx950) a wave's
+//        v_pk_mul_f32 d, x, r op_sel:[0,1]          (both halves of d use the HIGH word of r)
+// returns wrong values while ANOTHER kernel's waves execute certain MFMA instructions on the same CU.
+// Victim: registers only (optionally fed from an LDS read), checks itself against the exact product.  Aggressors: register-only
+// MFMA loops, 256 threads and 57 KB of LDS per workgroup (two workgroups per CU, so the victim's workgroups co-reside).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/pk_opsel_repro.hip -o tools/bin/pk_opsel_repro
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// bad[0] wrong values, bad[1] of those: low half == x0 * LOW word of r (op_sel ignored), bad[2]: d == {0, 0}
+template <int V>
+__global__ __launch_bounds__(256) void victim(unsigned* bad, int iters, float* samples) {
+    unsigned nb = 0, nlow = 0, nzero = 0;
+    const f32x2 x = {2.f, 4.f};
+    for (int it = 0; it < iters; ++it) {
+        const float a = (float)((threadIdx.x * 37 + it * 101 + blockIdx.x) % 1021 + 1), b = a + 1.f;
+        f32x2 r = {a, b}, d, e;
+        if (V == 0) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=&v"(d) : "v"(x), "v"(r)); e = f32x2{2.f * b, 4.f * b}; }
+        if (V == 1) { asm volatile("v_pk_mul_f32 %0, %1, %2" : "=&v"(d) : "v"(x), "v"(r)); e = f32x2{2.f * a, 4.f * b}; }
+        if (V == 2) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=&v"(d) : "v"(x), "v"(r)); e = f32x2{4.f * a, 4.f * b}; }
+        if (V == 3) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=&v"(d) : "v"(x), "v"(r)); e = f32x2{2.f * a, 4.f * a}; }
+        if (V == 4) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=&v"(d) : "v"(x), "v"(r)); e = f32x2{2.f + b, 4.f + b}; }
+        if (V == 5) { asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,1,0]" : "=&v"(d) : "v"(x), "v"(r)); e = f32x2{2.f * b + 2.f, 4.f * b + 4.f}; }
+        if (V == 6) { asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=&v"(d) : "v"(x), "v"(r)); e = f32x2{4.f, a}; }
+        const bool w0 = d[0] != e[0], w1 = d[1] != e[1];
+        nb += w0 + w1;
+        nlow += (w0 || w1) && (V == 0 ? d[0] == 2.f * a : false);
+        nzero += (w0 || w1) && d[0] == 0.f && d[1] == 0.f;
+        if ((w0 || w1) && samples) {                                // first few wrong results: r = {a, b}, expected e, got d
+            const unsigned k = atomicAdd(bad + 3, 1u);
+            if (k < 8) { float* q = samples + 8 * k; q[0] = a; q[1] = b; q[2] = e[0]; q[3] = e[1]; q[4] = d[0]; q[5] = d[1]; q[6] = (float)(threadIdx.x & 63); q[7] = (float)it; }
+        }
+    }
+    if (nb) { atomicAdd(bad, nb); atomicAdd(bad + 1, nlow); atomicAdd(bad + 2, nzero); }
+}
+
+template <int A>
+__global__ __launch_bounds__(256) void aggressor(float* out, int iters) {
+    extern __shared__ float pad[];                                  // occupancy only
+    const int l = threadIdx.x;
+    float s = 0;
+    if (A == 0) {                                                   // v_mfma_f32_32x32x16_bf16
+        bf16x8 av, bv;
+        for (int i = 0; i < 8; ++i) { av[i] = (__bf16)(0.01f * (l + i)); bv[i] = (__bf16)(0.02f * (l - i)); }
+        f32x16 acc[2] = {};
+        for (int it = 0; it < iters; ++it)
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
+        for (int i = 0; i < 16; ++i) s += acc[0][i] + acc[1][i];
+    } else if (A == 1) {                                            // v_mfma_f32_16x16x4_f32
+        f32x4 acc[4] = {};
+        for (int it = 0; it < iters; ++it)
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(0.01f * l, 0.5f + j, acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][3];
+    } else if (A == 2) {                                            // v_mfma_f32_16x16x32_bf16
+        bf16x8 av, bv;
+        for (int i = 0; i < 8; ++i) { av[i] = (__bf16)(0.01f * (l + i)); bv[i] = (__bf16)(0.02f * (l - i)); }
+        f32x4 acc[4] = {};
+        for (int it = 0; it < iters; ++it)
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][3];
+    } else if (A == 3) {                                            // v_mfma_f32_32x32x8_bf16_1k (the gfx90a-era shape)
+        s16x4 av = {(short)l, 1, 2, 3}, bv = {3, 2, 1, (short)l};
+        f32x16 acc[2] = {};
+        for (int it = 0; it < iters; ++it)
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(av, bv, acc[j], 0, 0, 0);
+        for (int i = 0; i < 16; ++i) s += acc[0][i] + acc[1][i];
+    } else {                                                        // no MFMA: fp32 FMA chain
+        float a0 = 0.01f * l, a1 = 1.f;
+        for (int it = 0; it < iters * 8; ++it) { a0 = fmaf(a0, 0.999f, 0.1f); a1 = fmaf(a1, 1.001f, -0.1f); }
+        s = a0 + a1;
+    }
+    out[blockIdx.x * 256 + l] = s + (iters < 0 ? pad[l] : 0.f);
+}
+
+#define CK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(r_), __LINE__); return 2; } } while (0)
+float* g_samples = nullptr;
+template <int V> void run_victim(unsigned* bad, hipStream_t st) { hipLaunchKernelGGL(victim<V>, dim3(2048), dim3(256), 0, st, bad, 2000, g_samples); }
+template <int A> void run_aggr(float* out, hipStream_t st) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aggressor<A>), hipFuncAttributeMaxDynamicSharedMemorySize, 58368);
+    hipLaunchKernelGGL(aggressor<A>, dim3(4096), dim3(256), 58368, st, out, 4000);
+}
+
+int main(int argc, char** argv) {
+    const int trials = argc > 1 ? atoi(argv[1]) : 10;
+    unsigned* bad; float* out;
+    CK(hipMalloc(&bad, 16)); CK(hipMalloc(&out, 4096 * 256 * 4));
+    CK(hipMalloc(&g_samples, 64 * 4));
+    hipStream_t sA, sB;
+    CK(hipStreamCreate(&sA)); CK(hipStreamCreate(&sB));
+    const char* vn[] = {"v_pk_mul_f32 op_sel:[0,1]", "v_pk_mul_f32", "v_pk_mul_f32 op_sel:[1,0]", "v_pk_mul_f32 op_sel_hi:[1,0]", "v_pk_add_f32 op_sel:[0,1]",
+                        "v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_mov_b32 op_sel:[1,0]"};
+    const char* an[] = {"v_mfma_f32_32x32x16_bf16", "v_mfma_f32_16x16x4_f32", "v_mfma_f32_16x16x32_bf16", "v_mfma_f32_32x32x8_bf16_1k", "fp32 FMA chain (no MFMA)"};
+    void (*vf[])(unsigned*, hipStream_t) = {run_victim<0>, run_victim<1>, run_victim<2>, run_victim<3>, run_victim<4>, run_victim<5>, run_victim<6>};
+    void (*af[])(float*, hipStream_t) = {run_aggr<0>, run_aggr<1>, run_aggr<2>, run_aggr<3>, run_aggr<4>};
+    for (int v = 0; v < 7; ++v) {
+        CK(hipMemset(bad, 0, 16));
+        vf[v](bad, sA);
+        CK(hipDeviceSynchronize());
+        unsigned h[4];
+        CK(hipMemcpy(h, bad, 16, hipMemcpyDeviceToHost));
+        printf("%-30s alone: %u wrong values\n", vn[v], h[0]);
+        for (int ag = 0; ag < 5; ++ag) {
+            int bad_runs = 0; unsigned long tot = 0, low = 0, zero = 0;
+            for (int i = 0; i < trials; ++i) {
+                CK(hipMemset(bad, 0, 16));
+                af[ag](out, sB);
+                vf[v](bad, sA);
+                af[ag](out, sB);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(h, bad, 16, hipMemcpyDeviceToHost));
+                bad_runs += h[0] > 0; tot += h[0]; low += h[1]; zero += h[2];
+            }
+            printf("    beside %-28s: %2d of %d runs wrong (%lu values; %lu 'op_sel ignored', %lu zero)\n", an[ag], bad_runs, trials, tot, low, zero);
+            if (h[0] && (v == 0 || v == 4)) {
+                float hs[64];
+                CK(hipMemcpy(hs, g_samples, 256, hipMemcpyDeviceToHost));
+                for (int k = 0; k < 8 && k < (int)h[3]; ++k)
+                    printf("        lane %2.0f it %4.0f: r = {%g, %g}  expected {%g, %g}  got {%g, %g}\n", hs[8 * k + 6], hs[8 * k + 7], hs[8 * k], hs[8 * k + 1], hs[8 * k + 2], hs[8 * k + 3], hs[8 * k + 4], hs[8 * k + 5]);
+            }
+        }
+    }
+    return 0;
+}
