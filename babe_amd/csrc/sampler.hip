@@ -33,6 +33,43 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// Observation-noise regularisation (posterior_sampling.SNR_observations, testing/blind_bwe_sampler.py:80-86 and :542-548):
+//     y += sqrt(var(y, -1) / snr) * noise        per clip, var = the unbiased sample variance, IN PLACE (the reference mutates the
+// observations at every call, so the noise accumulates over the sampling loop).  One workgroup of 1024 threads per clip: mean, then
+// the sum of squared deviations (both in double, two passes over the 1.4 MB clip out of L2), then the update.  An optional
+// regulariser off the benchmark's path (conf/tester/blind_bwe_2.yaml sets it): built for exactness, not for bandwidth.
+__global__ __launch_bounds__(1024) void add_obs_noise_kernel(float* __restrict__ y, long y_bs, const float* __restrict__ noise,
+                                                             long n_bs, float snr, long n) {
+    __shared__ double sh[16];
+    __shared__ double res;
+    float* p = y + (long)blockIdx.x * y_bs;
+    const float* q = noise + (long)blockIdx.x * n_bs;
+    auto block_sum = [&](double v) {
+        v = wave_sum(v);
+        __syncthreads();                                   // (sh / res of the previous call are no longer read)
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0;
+            for (int w = 0; w < 16; ++w) t += sh[w];
+            res = t;
+        }
+        __syncthreads();
+        return res;
+    };
+    double acc = 0;
+    for (long i = threadIdx.x; i < n; i += 1024) acc += (double)p[i];
+    const double mean = block_sum(acc) / (double)n;
+    acc = 0;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const double d = (double)p[i] - mean;
+        acc += d * d;
+    }
+    const float var = (float)(block_sum(acc) / (double)(n - 1));
+    const float sigma = sqrtf(var / snr);
+    for (long i = threadIdx.x; i < n; i += 1024) p[i] = p[i] + sigma * q[i];
+}
+
 // Alternative guidance distances of get_rec_grads (testing/blind_bwe_sampler.py:99-103).  r = y - rec is what the
 // filter / overlap-add kernels hand over; rec = y - r.
 // cosine: partial sums (rec.rec, rec.y, y.y) per block
@@ -197,6 +234,13 @@ extern "C" int babe_fir_same(const float* x, long x_bs, const float* taps, int n
     const size_t lds = (size_t)(ntaps + 1024 + ntaps - 1) * sizeof(float);
     hipLaunchKernelGGL(fir_same_kernel, dim3(cdiv(L, 1024), B), dim3(256), lds, (hipStream_t)stream, x, x_bs, taps,
                        ntaps, out, out_bs, L, adjoint);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_add_obs_noise(float* y, long y_bs, const float* noise, long noise_bs, float snr, int B, long n, void* stream) {
+    BABE_CHECK_ARG(y && noise && B > 0 && n > 1 && snr > 0.f, "add_obs_noise: bad arguments");
+    hipLaunchKernelGGL(add_obs_noise_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, y, y_bs, noise, noise_bs, snr, n);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

@@ -40,6 +40,7 @@ def _register():
         "babe_design_filter": [P, P, I, I, I, F, I, P],
         "babe_filter_fit": [P, P, P, I, I, I, F, I, C.POINTER(FitCfg), P],
         "babe_lincomb3": [P, F, P, F, P, F, P, Lg, P],
+        "babe_add_obs_noise": [P, Lg, P, Lg, F, I, Lg, P],
         "babe_sumsq_partial": [P, Lg, P, I, I, Lg, P],
         "babe_cos_partial": [P, Lg, P, Lg, P, I, I, Lg, P],
         "babe_stft_dist_partial": [P, P, P, P, I, I, I, I, I, P],
@@ -62,6 +63,15 @@ def lincomb(out, a, x, b=0.0, y=None, c=0.0, z=None):
     assert x.is_contiguous() and out.is_contiguous() and (y is None or y.is_contiguous()) and (z is None or z.is_contiguous())
     check(lib().babe_lincomb3(ptr(out), a, ptr(x), b, ptr(y), c, ptr(z), n, stream()), "lincomb3")
     return out
+
+
+def add_obs_noise(y, noise, snr):
+    """y[b] += sqrt(var(y[b]) / snr) * noise[b] IN PLACE (get_rec_grads :80-86, fit_params :542-548); snr linear."""
+    _register()
+    B, L = y.shape
+    assert y.stride(1) == 1 and noise.stride(1) == 1 and noise.shape == y.shape
+    check(lib().babe_add_obs_noise(ptr(y), y.stride(0), ptr(noise), noise.stride(0), float(snr), B, L, stream()), "add_obs_noise")
+    return y
 
 
 def fir_same(x, taps, adjoint=False):

@@ -23,7 +23,7 @@ import os
 
 import torch
 
-from ..stft import STFTOps, fir_same, lincomb, make_fit_cfg, mask_blend
+from ..stft import STFTOps, add_obs_noise, fir_same, lincomb, make_fit_cfg, mask_blend
 from .._lib import check, lib, ptr, stream
 
 
@@ -70,8 +70,13 @@ class BlindSampler:
             mode = (2 if sdist.get("logmag", False) else 1) if sdist.mag else 0
             self.stft_dist = dict(nfft=int(sdist.nfft), mode=mode, weight=ps.freq_weighting)
         self.smoothl1_beta = ps.get("smoothl1_beta", 1.0)
-        if ps.get("SNR_observations", "None") != "None" or bb.get("sigma_den_estimate", 0):
-            raise NotImplementedError("observation-noise regularisation (SNR_observations / sigma_den_estimate)")
+        # observation-noise regularisation (get_rec_grads :80-86, fit_params :542-552; conf/tester/blind_bwe_2.yaml sets
+        # SNR_observations: 50): the observations receive fresh noise IN PLACE before every fit and before every guidance
+        # evaluation, and the fit may see a noisy copy of the denoised estimate.  The draws interleave with the step noise, so
+        # these modes run the single-stream loop (no lanes, no graphs) and draw in the reference's order.
+        snr_db = ps.get("SNR_observations", "None")
+        self.obs_snr = None if snr_db == "None" else 10.0 ** (float(snr_db) / 10.0)
+        self.sigma_den = float(bb.get("sigma_den_estimate", 0) or 0)
 
         assert batch_semantics in ("per_clip", "reference")
         self.batch_semantics = batch_semantics
@@ -158,6 +163,21 @@ class BlindSampler:
         B, L = x.shape
         x_den = self.get_denoised_estimate(x, t, lane)
         cskip, cout, cin = self._c
+        specX_fit = None
+        if y is not None and (self.obs_snr is not None or (blind and self.sigma_den)):
+            # reference order of the draws inside one evaluation: fit_params (y, then the denoised estimate), get_rec_grads (y)
+            if blind:
+                if self.obs_snr is not None:
+                    add_obs_noise(y, self._randn(y.shape, y.device).contiguous(), self.obs_snr)
+                    specY = st.stft(y)
+                if self.sigma_den:
+                    den_fit = lincomb(torch.empty_like(x_den), 1.0, x_den, self.sigma_den, self._randn(x_den.shape, x_den.device).contiguous())
+                    specX_fit = st.stft(den_fit)
+                else:
+                    specX_fit = st.stft(x_den)
+                filter_params, self.last_n_iter = self.fit_params(specX_fit, specY, filter_params)
+            if self.obs_snr is not None:
+                add_obs_noise(y, self._randn(y.shape, y.device).contiguous(), self.obs_snr)
         if y is None:
             # unconditional (get_score :160-170): d = -t*(x_den - x)/t^2
             return lincomb(torch.empty_like(x), 1.0 / float(t), x, -1.0 / float(t), x_den), x_den, filter_params
@@ -188,7 +208,7 @@ class BlindSampler:
             g_den = fir_same(seed, self.fir_taps, adjoint=True)
         else:
             specX = st.stft(x_den)
-            if blind:
+            if blind and specX_fit is None:
                 filter_params, self.last_n_iter = self.fit_params(specX, specY, filter_params)
             H = st.design_filter(filter_params)                     # [P,nbins]
             Hq = H if H.shape[0] == B else H[0]
@@ -252,6 +272,8 @@ class BlindSampler:
         if y is not None:
             device = y.device
             y = y.contiguous().float()
+            if self.obs_snr is not None:
+                y = y.clone()                  # the observation noise is added in place: never to the caller's tensor
             shape = y.shape
         B, L = shape
         with torch.cuda.device(device):
@@ -306,7 +328,7 @@ class BlindSampler:
     def _use_lanes(self, B, y, rid, filter_params):
         return (self.LANES > 1 and B >= 2 and y is not None and not rid and self.batch_semantics == "per_clip" and
                 getattr(self.model, "supports_lanes", False) and
-                self.ar_mask is None and self.dc is None and
+                self.ar_mask is None and self.dc is None and self.obs_snr is None and not self.sigma_den and
                 self.fir_taps is None and filter_params.shape[0] == B)
 
     def _lane_step(self, ln, i, t, gamma, noise, blind, snoise, half):

@@ -264,6 +264,10 @@ int babe_fir_same(const float* x, long x_bs, const float* taps, int ntaps, float
 /* out = a*x + b*y + c*z (y, z optional) over n elements */
 int babe_lincomb3(float* out, float a, const float* x, float b, const float* y, float c, const float* z, long n,
                   void* stream);
+/* y[b] += sqrt(var(y[b]) / snr) * noise[b] in place, var = unbiased sample variance over the n samples of clip b; snr is the
+ * LINEAR ratio 10^(SNR_observations / 10).  Replaces the observation-noise lines of get_rec_grads and fit_params
+ * (testing/blind_bwe_sampler.py:80-86, :542-548; conf/tester/blind_bwe_2.yaml SNR_observations: 50). */
+int babe_add_obs_noise(float* y, long y_bs, const float* noise, long noise_bs, float snr, int B, long n, void* stream);
 /* out[b][i] = m[i]*a[b][i] + (1-m[i])*b_[b][i]; a or b_ may be NULL (= 0); mask stride mask_bs (0: shared).
  * Mask-mixed degradation and the replacement data-consistency step of predict_bwe_AR (blind_bwe_sampler.py:63-73,280-300) */
 int babe_mask_blend(float* out, const float* mask, long mask_bs, const float* a, const float* b_, int B, long n,

@@ -18,9 +18,13 @@ class OracleBlindSampler:
                  nfft=4096, fc_init=(280, 285, 290, 295, 300), A_init=(-15, -17, -20, -25, -30),
                  mu=(1000.0, 10.0), tol=(5e-3, 5e-3), max_iter=100, fcmin=20.0, Amin=-50.0,
                  weighting="sqrt", filter_out_cqt_DC_Nyq=True, norm=2, smoothl1_beta=1.0, stft_distance=None,
-                 data_consistency=False):
-        """stft_distance: None or dict(nfft=, weight=, mag=, logmag=) = posterior_sampling.stft_distance.use (:105-115)."""
+                 data_consistency=False, SNR_observations=None, sigma_den_estimate=0.0):
+        """stft_distance: None or dict(nfft=, weight=, mag=, logmag=) = posterior_sampling.stft_distance.use (:105-115).
+        SNR_observations (dB) / sigma_den_estimate: the observation-noise regularisation of get_rec_grads :80-86 and
+        fit_params :542-552 - y receives fresh noise IN PLACE before every fit and every guidance evaluation."""
         self.net, self.cqt, self.p = net, cqt, edm_params
+        self.obs_snr = None if SNR_observations is None else 10.0 ** (SNR_observations / 10.0)
+        self.sigma_den = sigma_den_estimate
         self.norm, self.smoothl1_beta, self.stft_distance = norm, smoothl1_beta, stft_distance
         self.data_consistency = data_consistency          # posterior_sampling.data_consistency (conf/tester/blind_bwe_DC.yaml)
         self.fs, self.audio_len, self.T, self.order, self.xi = fs, audio_len, T, order, xi
@@ -55,7 +59,11 @@ class OracleBlindSampler:
         s = self.xi / (torch.linalg.norm(g) / self.audio_len ** 0.5 + 1e-6)
         return s * g / t
 
-    def evaluate(self, x, t, y, params, blind=True, timers=None):
+    def _obs_noise(self, y, draw):
+        sigma = torch.sqrt(torch.var(y, -1) / self.obs_snr).unsqueeze(-1)          # :81-86, :543-548
+        y += sigma * draw()
+
+    def evaluate(self, x, t, y, params, blind=True, timers=None, draw=None):
         """One score evaluation. Returns score, x_den (detached), new params.
         timers: optional dict accumulating wall seconds of the components (bench.py's cpu_baseline split):
         'unet_fwd' (denoiser forward incl. CQT + high-pass), 'fit' (fit_params), 'filter' (filter apply + norm),
@@ -68,7 +76,12 @@ class OracleBlindSampler:
         t1 = tick()
         xd2 = x_den.detach().clone()
         if blind:
-            params, _ = U.fit_params(xd2, y, params, **self.fit_kw)
+            if self.obs_snr is not None:
+                self._obs_noise(y, draw)
+            den_fit = xd2 + draw() * self.sigma_den if self.sigma_den else xd2          # :551-552
+            params, _ = U.fit_params(den_fit, y, params, **self.fit_kw)
+        if self.obs_snr is not None:
+            self._obs_noise(y, draw)
         t2 = tick()
         if timers is None:
             rg = self.rec_grads(x_den, y, x, t, params)
@@ -95,24 +108,28 @@ class OracleBlindSampler:
         p = self.p
         if params is None:
             params = torch.tensor([list(self.fc_init), list(self.A_init)], dtype=torch.float32)
+        it = iter(noises)                       # the reference's draw order: prior, then per step the step noise followed by
+        draw = lambda: next(it)                 # the observation-noise draws of that step's evaluations (if enabled)
+        if self.obs_snr is not None:
+            y = y.clone()                       # (noise is added in place)
         if self.start_sigma is None:
             t = E.schedule(p, self.T)
-            x = noises[0] * t[0]
+            x = draw() * t[0]
         else:
             t = E.schedule(p, self.T, self.start_sigma)
-            x = y + noises[0] * t[0]
+            x = y + draw() * t[0]
         gam = E.gamma(p, t)
         for i in range(self.T):
             t_hat = t[i] + gam[i] * t[i]
-            x_hat = x + ((t_hat ** 2 - t[i] ** 2) ** 0.5) * noises[1 + i]
-            score, xden, params = self.evaluate(x_hat, t_hat, y, params, blind)
+            x_hat = x + ((t_hat ** 2 - t[i] ** 2) ** 0.5) * draw()
+            score, xden, params = self.evaluate(x_hat, t_hat, y, params, blind, draw=draw)
             d = -t_hat * score
             h = t[i + 1] - t_hat
             if record is not None:
                 record.append(dict(x_hat=x_hat.clone(), t_hat=t_hat.clone(), x_den=xden.clone(), params=params.clone()))
             if t[i + 1] != 0 and self.order == 2:
                 x_prime = x_hat + h * d
-                score2, _, params = self.evaluate(x_prime, t[i + 1], y, params, blind)
+                score2, _, params = self.evaluate(x_prime, t[i + 1], y, params, blind, draw=draw)
                 d2 = -t[i + 1] * score2
                 x = x_hat + h * (0.5 * d + 0.5 * d2)
             else:

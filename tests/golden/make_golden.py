@@ -1074,8 +1074,40 @@ def g22():
         out[f"x_{key}"] = xr
     save("edm_sampler_modes.npz", seed=5151, res_a=0.3, **out)
 
+def g23():
+    """testing/blind_bwe_sampler.py predict_blind_bwe with the observation-noise regularisation on: posterior_sampling.SNR_observations
+    (conf/tester/blind_bwe_2.yaml:120 sets 50; get_rec_grads :80-86, fit_params :542-548: y += sqrt(var(y)/snr) randn IN PLACE, before
+    every fit and every guidance evaluation) and blind_bwe.sigma_den_estimate (:551-552: the fit sees a noisy copy of the
+    denoised estimate).  Same reduced network, observation recipe and schedule as the B = 1 blind goldens, T = 3; draws in the
+    reference's order: prior, then per step the step noise followed by (fit: y, denoised estimate; guidance: y) per evaluation."""
+    args = small_args(T=3)
+    args.tester.posterior_sampling.start_sigma = 0.05
+    args.tester.posterior_sampling.SNR_observations = 30      # (the shipped value is 50: 30 makes a wrong draw order visible)
+    args.tester.blind_bwe.sigma_den_estimate = 0.005
+    args.tester.blind_bwe.optimization.mu = [100, 1]          # keeps the fit contractive (see g13)
+    net, sd = build_ref_net(args)
+    L = args.exp.audio_len
+    with quiet():
+        s = samp_mod.BlindSampler(ResidualNetRef(net, 0.3, args.tester.diff_params.sigma_data), edm_mod.EDM(args), args)
+    g = torch.Generator().manual_seed(2323)
+    y = synth_obs(L, args.exp.sample_rate, g)
+    ndraw = 1 + 3 + 3 * 5                                   # prior + 3 steps + 5 evaluations x (fit y, fit den, guidance y)
+    noises = [torch.randn(1, L, generator=g) for _ in range(ndraw)]
+    it = iter(noises)
+    orig_randn = torch.randn
+    torch.randn = lambda *a, **k: next(it)
+    yy = y.clone()
+    try:
+        with quiet(), contextlib.redirect_stderr(io.StringIO()):
+            xres, fp, data_den, t, data_filt = s.predict_blind_bwe(yy, rid=True)
+    finally:
+        torch.randn = orig_randn
+    assert next(it, None) is None, "draw count"
+    save("sampler_obs_noise.npz", seed=2323, res_a=0.3, start_sigma=0.05, snr_db=30, sigma_den=0.005, mu=np.array([100.0, 1.0]), ndraw=ndraw, y=y, y_after=yy,
+         x=xres, filter_params=fp, t=t, data_filters=data_filt, data_denoised_sub16=data_den[:, :, ::16])
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23"]
     for w in which:
         globals()[w]()

@@ -382,6 +382,48 @@ def test_blind_sampler_B2_reference_batch_semantics_vs_golden():
     assert params_close(fp, s["filter_params"])
 
 
+def test_add_obs_noise_matches_the_reference_formula():
+    """babe_add_obs_noise: y += sqrt(var(y, -1) / snr) * noise in place, per clip (blind_bwe_sampler.py:80-86)."""
+    from babe_amd.stft import add_obs_noise
+    g = torch.Generator().manual_seed(7)
+    y = (torch.randn(3, 92092, generator=g) * torch.tensor([[0.05], [0.2], [1.0]]) + 0.01).cuda()
+    n = torch.randn(3, 92092, generator=g).cuda()
+    snr = 10.0 ** (30 / 10)
+    want = y.cpu() + torch.sqrt(torch.var(y.cpu(), -1) / snr).unsqueeze(-1) * n.cpu()
+    got = add_obs_noise(y, n, snr)
+    assert got.data_ptr() == y.data_ptr()
+    assert rel(got, want) < 1e-6
+
+
+def test_blind_sampler_observation_noise_regularisation_vs_golden():
+    """posterior_sampling.SNR_observations + blind_bwe.sigma_den_estimate (conf/tester/blind_bwe_2.yaml; get_rec_grads :80-86,
+    fit_params :542-552): noise added to the observations in place before every fit and every guidance evaluation, the fit on a
+    noisy denoised estimate; 19 draws in the reference's order, vs the imported reference (G23)."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    s = load("sampler_obs_noise.npz")
+    g, args, net = small_net(T=3, start_sigma=float(s["start_sigma"]))
+    args.tester.blind_bwe.optimization.mu = [float(v) for v in s["mu"]]
+    args.tester.posterior_sampling.SNR_observations = float(s["snr_db"])
+    args.tester.blind_bwe.sigma_den_estimate = float(s["sigma_den"])
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(L, generator=gen)                      # the draw that made the observation
+    noises = [torch.randn(1, L, generator=gen) for _ in range(int(s["ndraw"]))]
+    smp = BlindSampler(ResidualNet(net, float(s["res_a"]), 0.063), EDM(args), args)
+    it = iter(noises)
+    smp._randn = lambda shape, device: next(it).to(device)
+    y = s["y"].cuda()
+    x, fp, dden, t, dfil = smp.predict_blind_bwe(y, rid=True)
+    assert next(it, None) is None                          # every draw consumed, none missing
+    assert torch.equal(y.cpu(), s["y"])                    # the caller's tensor is not touched (the reference mutates it)
+    for i in range(3):
+        assert rel(dden[i][:, ::16], s["data_denoised_sub16"][i]) < 1e-3, i
+        assert params_close(dfil[i], s["data_filters"][i]), (i, dfil[i], s["data_filters"][i])
+    assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 2e-3
+    assert params_close(fp, s["filter_params"])
+
+
 def test_predict_unconditional_and_predict_bwe_firwin_vs_reference_golden():
     """BlindSampler.predict_unconditional (:366-374) and BlindSampler.predict_bwe(..., 'firwin') (:306-364) through
     predict (:406-498): rid=True returns (x, guided Tweedie estimates, scores, t) like the reference."""

@@ -279,6 +279,33 @@ def test_sampler_stft_domain_guidance_distances(tag, kw):
     assert rel(x, s[f"x_{tag}"]) < 1e-3 and params_close(fp, s[f"filter_params_{tag}"])
 
 
+def test_sampler_observation_noise_regularisation():
+    """posterior_sampling.SNR_observations = 50 (conf/tester/blind_bwe_2.yaml) + blind_bwe.sigma_den_estimate: y += sqrt(var(y)/snr)
+    randn IN PLACE before every fit (:542-548) and every guidance evaluation (:80-86), the fit on a noisy denoised estimate
+    (:551-552); 19 draws in the reference's order (G23)."""
+    g, sd, cqt = small_net()
+    s = load("sampler_obs_noise.npz")
+    L = 92092
+    a = float(s["res_a"])
+    p = E.EDMParams(0.063, 1e-4, 1.0, 8, Schurn=10, Stmin=0, Stmax=50, Snoise=1.0)
+    net = lambda x, cn: a * UN.unet_forward(sd, CFG, cqt, x, cn) + (torch.exp(4 * cn) / 0.063) * x
+    smp = OracleBlindSampler(net, cqt, p, fs=22050, audio_len=L, T=3, start_sigma=float(s["start_sigma"]),
+                             mu=tuple(float(v) for v in s["mu"]), SNR_observations=float(s["snr_db"]),
+                             sigma_den_estimate=float(s["sigma_den"]))
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(L, generator=gen)                      # the draw that made the observation
+    noises = [torch.randn(1, L, generator=gen) for _ in range(int(s["ndraw"]))]
+    rec = []
+    y = s["y"].clone()
+    x, fp = smp.predict_blind_bwe(y, noises, record=rec)
+    assert torch.equal(y, s["y"])                          # (the oracle works on a copy; the reference mutated its argument:)
+    assert float((s["y_after"] - s["y"]).pow(2).mean().sqrt()) > 0
+    for i in range(3):
+        assert rel(rec[i]["x_den"][:, ::16], s["data_denoised_sub16"][i]) < 1e-3, i
+        assert params_close(rec[i]["params"], s["data_filters"][i]), i
+    assert rel(x, s["x"]) < 1e-3 and params_close(fp, s["filter_params"])
+
+
 def test_sampler_data_consistency():
     """posterior_sampling.data_consistency=True (conf/tester/blind_bwe_DC.yaml, bwe_formal_1000_DC.yaml): the replacement step
     of data_consistency_step_classic :63-73 after every score evaluation; blind and known-filter T=3 runs (G18)."""
