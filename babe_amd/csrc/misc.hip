@@ -130,6 +130,32 @@ __global__ __launch_bounds__(256) void axpby4d_kernel(const float* __restrict__ 
     }
 }
 
+// out = alpha*x + beta*y over the same [B][C] planes (out may be a strided sub-view; x, y dense or strided): the residual merge
+// (x + h)/sqrt2 at the end of a ResnetBlock without res_conv (networks/cqtdiff+.py:493) in ONE pass - it was axpby(z -> out) followed
+// by axpby(x, out += ...), 20 bytes per element instead of 12.  Rounding as the two-pass form: fl(fl(alpha x) + fl(beta y)).
+__global__ __launch_bounds__(256) void axpby2_4d_kernel(const float* __restrict__ xin, long x_bs, long x_cs,
+                                                        const float* __restrict__ yin, long y_bs, long y_cs,
+                                                        float* __restrict__ out, long out_bs, long out_cs, int C, long n,
+                                                        float alpha, float beta) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.y / C, c = blockIdx.y % C;
+    const float* x = xin + (long)b * x_bs + (long)c * x_cs;
+    const float* y = yin + (long)b * y_bs + (long)c * y_cs;
+    float* o = out + (long)b * out_bs + (long)c * out_cs;
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i), yv = *reinterpret_cast<const f32x4*>(y + i);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma clang fp contract(off)                     // (HIP's __fmul_rn / __fadd_rn are plain operators: they would be fused)
+            const float p = alpha * xv[e], q = beta * yv[e];
+            v[e] = p + q;
+        }
+        *reinterpret_cast<f32x4*>(o + i) = v;
+    }
+}
+
 // one wave per output row j, all batches
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ out, int B,
@@ -181,6 +207,24 @@ extern "C" int babe_axpby4d(const float* in, long in_bs, long in_cs, float* out,
         hipLaunchKernelGGL(axpby4d_kernel<1>, dim3(bx, B * C), dim3(256), 0, (hipStream_t)stream, in, in_bs, in_cs, out,
                            out_bs, out_cs, C, n, alpha, beta);
     }
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_axpby2_4d(const float* x, long x_bs, long x_cs, const float* y, long y_bs, long y_cs, float* out, long out_bs,
+                              long out_cs, int B, int C, int F, int T, float alpha, float beta, void* stream) {
+    BABE_CHECK_ARG(x && y && out && B > 0 && C > 0 && F > 0 && T > 0, "axpby2_4d: bad arguments");
+    BABE_CHECK_ARG((long)B * C <= 65535, "axpby2_4d: grid too large");
+    const long n = (long)F * T;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    BABE_CHECK_ARG(n % 4 == 0 && al16(x) && al16(y) && al16(out) && x_bs % 4 == 0 && x_cs % 4 == 0 && y_bs % 4 == 0 && y_cs % 4 == 0 &&
+                       out_bs % 4 == 0 && out_cs % 4 == 0,
+                   "axpby2_4d: planes must be 16-byte aligned with F*T %% 4 == 0 (use two babe_axpby4d calls otherwise)");
+    BabeProfScope prof(BABE_SLOT_AXPBY, 12.0 * B * C * (double)n, 0, 0, stream);
+    int bx = cdiv(n / 4, 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(axpby2_4d_kernel, dim3(bx, B * C), dim3(256), 0, (hipStream_t)stream, x, x_bs, x_cs, y, y_bs, y_cs, out, out_bs,
+                       out_cs, C, n, alpha, beta);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

@@ -168,8 +168,7 @@ class UnetEngine:
         if blk.res_conv is not None:
             ops.conv2d(x, blk.res_conv, out, x2=x2, res=z, alpha=RS2, rbeta=RS2)
         else:
-            ops.axpby(z, out, alpha=RS2)
-            ops.axpby(x, out, alpha=RS2, beta=1.0)
+            ops.axpby2(z, x, out, RS2, RS2)                  # (x + h)/sqrt2 in one pass
         blk.saved = saved
         return out
 

@@ -321,6 +321,25 @@ def axpby(x, out, alpha=1.0, beta=0.0):
     return out
 
 
+AXPBY2 = os.environ.get("BABE_AXPBY2", "1") != "0"          # 0: the two-pass form (A/B switch)
+
+
+def axpby2(x, y, out, alpha, beta):
+    """out = alpha*x + beta*y in one pass over [B,C,F,T] views (falls back to two axpby calls for unaligned views)."""
+    assert x.shape == out.shape and y.shape == out.shape
+    B, Cc, F, T = x.shape
+    xp, xbs, xcs = _view(x)
+    yp, ybs, ycs = _view(y)
+    op, obs, ocs = _view(out)
+    aligned = (F * T) % 4 == 0 and all(v % 4 == 0 for v in (xbs, xcs, ybs, ycs, obs, ocs)) and \
+        all(t.data_ptr() % 16 == 0 for t in (x, y, out))
+    if not (aligned and AXPBY2):
+        axpby(x, out, alpha=alpha)
+        return axpby(y, out, alpha=beta, beta=1.0)
+    check(lib().babe_axpby2_4d(xp, xbs, xcs, yp, ybs, ycs, op, obs, ocs, B, Cc, F, T, alpha, beta, stream()), "axpby2_4d")
+    return out
+
+
 def linear(x, W, bias, relu=False, out=None):
     B, K = x.shape
     J = W.shape[0]

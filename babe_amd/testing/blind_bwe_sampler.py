@@ -31,6 +31,8 @@ class BlindSampler:
     NBLK = 64
     SCORE_MODE = 0          # guidance scaling of blind_bwe_sampler.py:125-135
 
+    obs_snr, sigma_den = None, 0.0        # (class defaults: testing/edm_sampler.Sampler has no observation-noise options)
+
     def __init__(self, model, diff_params, args, rid=False, batch_semantics="per_clip", noise_device="cpu",
                  max_segments_in_flight=32):
         """max_segments_in_flight: with per-clip semantics a larger batch is restored in sub-batches of at most this many

@@ -152,6 +152,10 @@ int babe_resample(const float* in, long in_bs, long in_cs, float* out, long out_
  * (a+b)/sqrt2 residual merges, cqtdiff+.py:769-774,794,814-822) */
 int babe_axpby4d(const float* in, long in_bs, long in_cs, float* out, long out_bs, long out_cs,
                  int B, int C, int F, int T, float alpha, float beta, void* stream);
+/* out = alpha*x + beta*y in one pass (ResnetBlock's (x + h)/sqrt2 without res_conv, cqtdiff+.py:493); every view 16-byte aligned,
+ * F*T % 4 == 0 */
+int babe_axpby2_4d(const float* x, long x_bs, long x_cs, const float* y, long y_bs, long y_cs, float* out, long out_bs,
+                   long out_cs, int B, int C, int F, int T, float alpha, float beta, void* stream);
 
 /* ---- small dense: out[b][j] = act(sum_k x[b][k] W[j][k] + bias[j]); Linear :36-40, RFF_MLP :184-211 */
 int babe_linear(const float* x, const float* W, const float* bias, float* out, int B, int K, int J,

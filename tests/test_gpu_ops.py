@@ -356,6 +356,24 @@ def test_axpby_linear_rff(ops):
     assert float((ops.rff(cn.cuda(), fr.cuda()).cpu() - ref).abs().max()) < 2e-4
 
 
+def test_axpby2_is_the_two_pass_residual_merge_bit_for_bit(ops):
+    """babe_axpby2_4d (out = a x + b y in one pass, the (x + h)/sqrt2 merge of cqtdiff+.py:493) == axpby(x -> out, a) followed by
+    axpby(y, out, b, 1), incl. a strided frequency sub-view as the destination and the unaligned fallback."""
+    g = torch.Generator().manual_seed(19)
+    rs2 = 1.0 / math.sqrt(2.0)
+    for (B, C, F, T, f0) in [(2, 8, 16, 64, 0), (1, 5, 12, 40, 8), (1, 3, 5, 6, 0)]:          # last: F*T % 4 != 0 -> fallback
+        x = torch.randn(B, C, F, T, generator=g).cuda()
+        y = torch.randn(B, C, F, T, generator=g).cuda()
+        big1 = torch.zeros(B, C, F + f0 + 4, T, device="cuda")
+        big2 = torch.zeros_like(big1)
+        o1, o2 = big1[:, :, f0:f0 + F, :], big2[:, :, f0:f0 + F, :]
+        ops.axpby(x, o1, alpha=rs2)
+        ops.axpby(y, o1, alpha=rs2, beta=1.0)
+        ops.axpby2(x, y, o2, rs2, rs2)
+        assert torch.equal(big1, big2), (B, C, F, T)
+        assert rel(o2, rs2 * (x.cpu() + y.cpu())) < 1e-6
+
+
 def test_unet_body_fwd_and_vjp_small():
     """UNet body (between CQT.fwd and CQT.bwd) on the HIP engine vs the oracle with autograd."""
     import os
