@@ -20,10 +20,31 @@
 #include "conv_common.h"
 #include <cstdlib>
 
+#ifndef C11_SYNC_AT_END
+#define C11_SYNC_AT_END 0          // 1: the round-2 form (one __syncthreads() = vmcnt(0) + barrier at the end of every slab)
+#endif
+
 namespace {
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr unsigned OOB11 = 0x80000000u;
+
+// LDS-DMA as inline asm.  With the builtin, hipcc's wait insertion makes every LDS read wait for ALL pending LDS-DMA (no alias scopes
+// in LDS), i.e. vmcnt(0) in front of the first operand read after a slab's DMA was issued: the prefetch the ring exists for was
+// waited for at once (rounds 2-3 ran like that; only the CU's second workgroup hid the latency).  The asm form is invisible to
+// that pass; completion is the kernel's own counted s_waitcnt (see the K loop).  rs = {base lo, base hi, bytes, 0x00020000}.
+typedef int c11_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ c11_i32x4 c11_rsrc(const void* p, unsigned bytes) {
+    const unsigned long a = (unsigned long)p;
+    return c11_i32x4{(int)__builtin_amdgcn_readfirstlane((unsigned)a), (int)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu),
+                     (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000};
+}
+__device__ __forceinline__ void c11_dma16(c11_i32x4 rs, const float* lds_dst, unsigned voff) {
+#if __HIP_DEVICE_COMPILE__
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)LDS_PTR(lds_dst));
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(rs) : "memory");
+#endif
+}
 
 struct C11Geom {
     int CinP, CoutP, pt_log2, pr_log2, tiles_t;
@@ -46,6 +67,31 @@ __device__ __forceinline__ void conv11p_epilogue(const babe_conv_args& a, f32x16
     const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)(has_os ? a.oscale + (long)b * a.Cout : a.out), 0,
                                                                          has_os ? (unsigned)(a.Cout * 4) : 0u, 0x00020000);
     const unsigned ocs = (unsigned)a.out_cs * 4u, rcs = (unsigned)a.res_cs * 4u;
+    // per-position byte offsets of the WP column tiles (out of range when the position is padding)
+    unsigned lo[WP], lr[WP];
+#pragma unroll
+    for (int wp = 0; wp < WP; ++wp) {
+        const int p = (wave * WP + wp) * 32 + l31;
+        const int f = f0 + (p >> pt_log2);
+        const int t = t0 + (p & (PT - 1));
+        const bool pv = f < a.F && t < a.T;
+        const unsigned sp = (unsigned)(f * a.T + t) * 4u;
+        lo[wp] = pv ? (unsigned)(co0 + 4 * h) * ocs + sp : 0x80000000u;
+        lr[wp] = pv ? (unsigned)(co0 + 4 * h) * rcs + sp : 0x80000000u;
+    }
+    // The residual of group g + 1 (one (row tile, column tile) pair = 16 values per lane) is loaded while group g is scaled and
+    // stored: two groups of loads in flight per wave instead of one (the res-carrying layers - every VJP - are bound by this
+    // epilogue: 16 loads x 256 B per wave in flight is about 4.4 TB/s over the chip, which is where they sat).
+    float rv[2][16];
+    auto load_res = [&](int gidx, float (&dst)[16]) {
+        const int nt = gidx / WP, wp = gidx % WP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = nt * 32 + (r & 3) + 8 * (r >> 2);
+            dst[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr_, lr[wp] + (unsigned)cl * rcs, 0, 0));
+        }
+    };
+    if (has_res) load_res(0, rv[0]);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         // output scales of this lane's 16 channels (channel = co0 + nt*32 + (r & 3) + 8*(r >> 2) + 4*h), once per row tile
@@ -58,29 +104,16 @@ __device__ __forceinline__ void conv11p_epilogue(const babe_conv_args& a, f32x16
         }
 #pragma unroll
         for (int wp = 0; wp < WP; ++wp) {
-            const int p = (wave * WP + wp) * 32 + l31;
-            const int f = f0 + (p >> pt_log2);
-            const int t = t0 + (p & (PT - 1));
-            const bool pv = f < a.F && t < a.T;
-            const unsigned sp = (unsigned)(f * a.T + t) * 4u;
-            const unsigned lo = pv ? (unsigned)(co0 + 4 * h) * ocs + sp : 0x80000000u;
-            const unsigned lr = pv ? (unsigned)(co0 + 4 * h) * rcs + sp : 0x80000000u;
-            float rv[16];
-            if (has_res) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cl = nt * 32 + (r & 3) + 8 * (r >> 2);
-                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr_, lr + (unsigned)cl * rcs, 0, 0));
-                }
-            }
+            const int gidx = nt * WP + wp;
+            if (has_res && gidx + 1 < NT * WP) load_res(gidx + 1, rv[(gidx + 1) & 1]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cl = nt * 32 + (r & 3) + 8 * (r >> 2);
                 // (explicit rounding points: left to -ffp-contract the 128- and 256-position instantiations fused different
                 // pairs of these three operations and gave results one ulp apart for the same input)
                 float v = __fmul_rn(acc[nt][wp][r], os[r]);
-                if (has_res) v = __builtin_fmaf(a.rbeta, rv[r], v);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), ro, lo + (unsigned)cl * ocs, 0, 0);
+                if (has_res) v = __builtin_fmaf(a.rbeta, rv[gidx & 1][r], v);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), ro, lo[wp] + (unsigned)cl * ocs, 0, 0);
             }
         }
     }
@@ -121,7 +154,6 @@ __global__ __launch_bounds__(256, NPW == 2 ? 2 : 3) void conv11p_kernel(babe_con
     const float* p2 = a.in2 ? a.in2 + (long)b * a.in2_bs : p1;
     const int cs1 = (int)a.in_cs, cs2 = a.in2 ? (int)a.in2_cs : (int)a.in_cs;
     const int nb1 = split * cs1 * 4, nb2 = (a.Cin - split) * cs2 * 4;
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_packed, 0, g.CinP * g.CoutP * 4, 0x00020000);
 
     // per-thread DMA offsets: X piece v = float4 q of channel row ci_l;  W piece jj = float4 c4 of row ci_l
     int xoff1[XJ], xoff2[XJ];
@@ -143,19 +175,18 @@ __global__ __launch_bounds__(256, NPW == 2 ? 2 : 3) void conv11p_kernel(babe_con
         const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
         woff[jj] = idx < WF4 ? (unsigned)((row * g.CoutP + co0 + c4 * 4) * 4) : OOB11;
     }
+    const c11_i32x4 q1 = c11_rsrc(p1, (unsigned)nb1), q2 = c11_rsrc(p2, (unsigned)nb2), qw = c11_rsrc(a.w_packed, (unsigned)(g.CinP * g.CoutP * 4));
     auto dma_slab = [&](int ci0, float* buf) {
         const bool s2 = ci0 >= split;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(s2 ? p2 : p1), 0, s2 ? nb2 : nb1, 0x00020000);
+        const c11_i32x4 rs = s2 ? q2 : q1;
         const int so = (s2 ? (ci0 - split) * cs2 : ci0 * cs1) * 4;
 #pragma unroll
         for (int v = 0; v < XJ; ++v)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(buf + (v * 256 + wave * 64) * 4), 16,
-                                                     (unsigned)((s2 ? xoff2[v] : xoff1[v]) + so) | xbad[v], 0, 0, 0);
+            c11_dma16(rs, buf + (v * 256 + wave * 64) * 4, (unsigned)((s2 ? xoff2[v] : xoff1[v]) + so) | xbad[v]);
 #pragma unroll
         // (the whole offset is in the VGPR operand: the range check that zero-fills rows >= CinP covers only that one)
         for (int jj = 0; jj < WJ; ++jj)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(buf + XF + (jj * 256 + wave * 64) * 4), 16,
-                                                     woff[jj] + (unsigned)(ci0 * g.CoutP * 4), 0, 0, 0);
+            c11_dma16(qw, buf + XF + (jj * 256 + wave * 64) * 4, woff[jj] + (unsigned)(ci0 * g.CoutP * 4));
     };
 
     f32x16 acc[NT][NPW];
@@ -174,17 +205,19 @@ __global__ __launch_bounds__(256, NPW == 2 ? 2 : 3) void conv11p_kernel(babe_con
     // prologue: slabs 0 and 1 (a slab index beyond the last one is clamped: re-staged, never read)
     dma_slab(0, smem);
     dma_slab(nslab > 1 ? KC : 0, smem + BUF);
-    __syncthreads();
+    float* const sc_lds = smem + 3 * BUF;                   // [nslab * KC] in_scale of this batch item (HAS_ISC)
+    if (HAS_ISC)
+        for (int c = tid; c < nslab * KC; c += 256) sc_lds[c] = isp[c < a.Cin ? c : a.Cin - 1];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (the asm DMAs are invisible to __syncthreads()' waits)
 
     // in_scale of this lane's k index for the 8 K-steps of a slab, loaded one slab ahead (a scalar load inside the K-step
     // would stall every step on its latency)
     float scur[KC / 2], snext[KC / 2];
+    // (from an LDS copy of the batch item's Cin scales, made in the prologue: vector loads from global memory would sit in the
+    // same queue as the slab DMA, and hipcc's wait for them would be a wait for the prefetch)
     auto load_scales = [&](int ci0, float* dst) {
 #pragma unroll
-        for (int st = 0; st < KC / 2; ++st) {
-            const int c = ci0 + 2 * st + h;
-            dst[st] = HAS_ISC ? isp[c < a.Cin ? c : a.Cin - 1] : 1.f;
-        }
+        for (int st = 0; st < KC / 2; ++st) dst[st] = HAS_ISC ? sc_lds[ci0 + 2 * st + h] : 1.f;
     };
     if (HAS_ISC) load_scales(0, scur);
 
@@ -200,11 +233,25 @@ __global__ __launch_bounds__(256, NPW == 2 ? 2 : 3) void conv11p_kernel(babe_con
         const float* Xs = smem + rb * BUF;
         const float* Xn = smem + rn * BUF;
         const int jw = j + 2 < nslab ? j + 2 : nslab - 1;
-        dma_slab(jw * KC, smem + rw * BUF);
+        // (the scale loads are OLDER than the slab's DMA in the vector-memory queue: waiting for them leaves the DMA in flight)
         if (HAS_ISC) load_scales((j + 1 < nslab ? j + 1 : j) * KC, snext);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_slab(jw * KC, smem + rw * BUF);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int st = 0; st < KC / 2; ++st) {
             const int c = st & 1;
+#if !C11_SYNC_AT_END
+            if (st == KC / 2 - 1) {
+                // COUNTED wait (round 4): the workgroup synchronises before the LAST K-step of slab j, and each wave waits only for
+                // its part of slab j+1 (vmcnt(n) with n = the XJ + WJ DMA instructions of slab j+2, the youngest in the queue), so
+                // slab j+2 stays in flight across the barrier: two slabs of prefetch distance instead of the one that
+                // __syncthreads()' vmcnt(0) left.  Safe for the ring: the operands of this last step are already in registers
+                // (read during step KC/2 - 2, complete at lgkmcnt(0)), so after the barrier nobody reads slab j's buffer again,
+                // and the reads of slab j+1 below come after every wave's part of it has landed.
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XJ + WJ) : "memory");
+            }
+#endif
             if (st + 1 < KC / 2) {
                 AVec<NT>::ld(Xs + aoff + 2 * (st + 1) * BN, av[c ^ 1]);
 #pragma unroll
@@ -225,13 +272,18 @@ __global__ __launch_bounds__(256, NPW == 2 ? 2 : 3) void conv11p_kernel(babe_con
                 for (int wp = 0; wp < NPW; ++wp)
                     acc[nt][wp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][nt], bv[c][wp], acc[nt][wp], 0, 0, 0);
         }
+#if C11_SYNC_AT_END
         __syncthreads();                                   // slab j+2 landed (vmcnt(0)), slab j's buffer free
+#endif
         if (HAS_ISC) {
 #pragma unroll
             for (int st = 0; st < KC / 2; ++st) scur[st] = snext[st];
         }
         rb = rn;
     }
+#if !C11_SYNC_AT_END
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped re-stage of the last slab: nothing lands in LDS after the loop
+#endif
     conv11p_epilogue<NT, NPW>(a, acc, b, co0, f0, t0, g.pt_log2, wave, l31, h);
 #endif
 }
@@ -247,11 +299,12 @@ void launch11(const babe_conv_args& a, C11Geom g, hipStream_t s) {
     const int tiles_f = cdiv(a.F, 1 << g.pr_log2);
     constexpr int BN = NT * 32;
     constexpr int WJ = (16 * BN / 4 + 255) / 256;
-    const size_t lds = 3 * (size_t)(16 * 128 * NPW + WJ * 256 * 4) * 4;
+    const size_t lds = 3 * (size_t)(16 * 128 * NPW + WJ * 256 * 4) * 4 + (a.in_scale ? (size_t)((g.CinP + 15) / 16 * 16) * 4 : 0);
     dim3 grid(g.tiles_t * tiles_f, g.CoutP / BN, a.B);
     static std::atomic<unsigned long long> attr_done{0};
     if (babe_lds_optin(attr_done, {reinterpret_cast<const void*>(&conv11p_kernel<NT, NPW, true>),
-                                   reinterpret_cast<const void*>(&conv11p_kernel<NT, NPW, false>)}, (int)lds) != hipSuccess)
+                                   reinterpret_cast<const void*>(&conv11p_kernel<NT, NPW, false>)},
+                       (int)(3 * (size_t)(16 * 128 * NPW + WJ * 256 * 4) * 4 + 2048 * 4)) != hipSuccess)     // (+ up to 2048 in_scale values)
         return;
     if (a.in_scale) hipLaunchKernelGGL((conv11p_kernel<NT, NPW, true>), grid, dim3(256), lds, s, a, g);
     else hipLaunchKernelGGL((conv11p_kernel<NT, NPW, false>), grid, dim3(256), lds, s, a, g);
@@ -275,6 +328,7 @@ int babe_conv11p_supported(const babe_conv_args& a, int nt) {
     // the epilogue addresses out / res of a batch item through buffer descriptors with 32-bit offsets
     const long coP = (a.Cout + 31) / 32 * 32;
     if (coP * a.out_cs >= lim || (a.res && coP * a.res_cs >= lim)) return 0;
+    if (a.in_scale && a.Cin > 2032) return 0;                 // the LDS copy of the scales
     if ((long)a.F * a.T < 4096 && a.Cin < 256) return 0;     // tiny planes AND a short K loop: nothing to pipeline (the
                                                              // dense DFT stages, K ~ 2000 over a few hundred positions, qualify)
     return 1;
