@@ -178,6 +178,23 @@ class UnetEngine:
         B, _, Fq, T = g_out.shape
         N = blk.N
         beta = 1.0 if accumulate else 0.0
+        if (blk.res_conv is None and blk.proj_out is None and blk.proj_in is None and not accumulate and blk.nd > 0
+                and g_out.is_contiguous() and ops.AXPBY2):
+            # N -> N block (every main block of the encoder, the middle block): the residual path's RS2*g_out and the main path's
+            # c*gz are merged in ONE pass at the end (12 instead of 8 + 12 bytes per element).  For that g_out has to survive the
+            # chain: the first layer's gn_bwd reads it as its residual input and writes into a buffer of its own (same traffic),
+            # the later layers update that buffer in place.  Same arithmetic, same rounding as the two-pass form.
+            gz = self.buf(B, N, Fq, T)
+            da = self.scratch("a", B * N * Fq * T).view(B, N, Fq, T)
+            src = g_out
+            for d in reversed(range(blk.nd)):
+                z, stats, scale, gate = blk.saved[d]
+                ops.conv2d(src, blk.H[d], da, dil=blk.dil(d), transpose=True, in_scale=gate, alpha=RS2)
+                ops.gn_bwd(z, da, src, scale, stats, gz, RS2)
+                src = gz
+            ops.axpby2(g_out, gz, g_in, RS2, RS2)
+            blk.saved = None
+            return g_in
         # residual path
         if blk.res_conv is not None:
             ops.conv2d(g_out, blk.res_conv, g_in, transpose=True, alpha=RS2, rbeta=beta, res=g_in if accumulate else None)

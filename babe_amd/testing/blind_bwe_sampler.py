@@ -68,7 +68,8 @@ class BlindSampler:
         sdist = ps.get("stft_distance", None)
         if ps.norm == 2 and sdist is not None and sdist.use:          # same precedence as get_rec_grads :99-117
             if sdist.get("use_multires", False):
-                raise NotImplementedError("posterior_sampling.stft_distance.use_multires (auraloss multi-resolution loss)")
+                raise NotImplementedError("posterior_sampling.stft_distance.use_multires: dead code in the reference (get_rec_grads :108 calls "
+                                          "self.norm, which the sampler never defines)")
             mode = (2 if sdist.get("logmag", False) else 1) if sdist.mag else 0
             self.stft_dist = dict(nfft=int(sdist.nfft), mode=mode, weight=ps.freq_weighting)
         self.smoothl1_beta = ps.get("smoothl1_beta", 1.0)
