@@ -71,7 +71,8 @@ __device__ __forceinline__ float resample_one(const float* __restrict__ x, int n
 template <int V, int VI>
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, long in_bs, long in_cs,
                                                        float* __restrict__ out, long out_bs, long out_cs, int C, int F,
-                                                       int T, int mode, float alpha, float beta, int tout_shift) {
+                                                       int T, int mode, float alpha, float beta, int tout_shift,
+                                                       const float* res, long res_bs, long res_cs) {
     const int b = blockIdx.y / C, c = blockIdx.y % C;
     const int Tin = (mode == 0 || mode == 1) ? T : (mode == 2 ? T / 2 : 2 * T);
     const int Tout = (mode == 0) ? T / 2 : (mode == 1 ? 2 * T : T);
@@ -83,6 +84,8 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     const int n0 = (int)(i - (unsigned)f * (unsigned)Tout);
     const float* x = in + (long)b * in_bs + (long)c * in_cs + (long)f * Tin;
     float* y = out + (long)b * out_bs + (long)c * out_cs + (long)f * Tout + n0;
+    // beta * (what is accumulated onto): `out` itself, or a separate tensor `res` (babe_resample_res: saves the copy res -> out)
+    const float* ry = res ? res + (long)b * res_bs + (long)c * res_cs + (long)f * Tout + n0 : y;
     float s[V];
     if constexpr (V == 4) {
         // The 4 outputs share one register window of the source row.  Interior threads read it with 16- / 8-byte loads;
@@ -213,17 +216,20 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     if constexpr (V == 4) {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4 o = {s[0], s[1], s[2], s[3]};
-        if (beta != 0.f) o += beta * *reinterpret_cast<const f32x4*>(y);
+        if (beta != 0.f) o += beta * *reinterpret_cast<const f32x4*>(ry);
         *reinterpret_cast<f32x4*>(y) = o;
     } else {
-        y[0] = (beta != 0.f) ? s[0] + beta * y[0] : s[0];
+        y[0] = (beta != 0.f) ? s[0] + beta * ry[0] : s[0];
     }
 }
 }  // namespace
 
-extern "C" int babe_resample(const float* in, long in_bs, long in_cs, float* out, long out_bs, long out_cs, int B,
-                             int C, int F, int T, int mode, float alpha, float beta, void* stream) {
+static int resample_launch(const float* in, long in_bs, long in_cs, float* out, long out_bs, long out_cs, const float* res,
+                           long res_bs, long res_cs, int B, int C, int F, int T, int mode, float alpha, float beta, void* stream) {
     BABE_CHECK_ARG(in && out && B > 0 && C > 0 && F > 0, "resample: bad arguments");
+    BABE_CHECK_ARG(!res || ((((uintptr_t)res & 15) == 0) && res_bs % 4 == 0 && res_cs % 4 == 0 && (((uintptr_t)out & 15) == 0) &&
+                            out_bs % 4 == 0 && out_cs % 4 == 0),
+                   "resample_res: res / out must be 16-byte aligned views");
     BABE_CHECK_ARG(mode >= 0 && mode <= 3, "resample: bad mode %d", mode);
     BABE_CHECK_ARG(T >= 8 && (T % 2) == 0, "resample: T=%d unsupported (need even T >= 8)", T);
     BABE_CHECK_ARG((long)B * C <= 65535, "resample: grid too large");
@@ -240,13 +246,25 @@ extern "C" int babe_resample(const float* in, long in_bs, long in_cs, float* out
     const bool vin = (Tin % 4 == 0) && (((uintptr_t)in & 15) == 0) && (in_bs % 4 == 0) && (in_cs % 4 == 0);
     if (v4 && vin)
         hipLaunchKernelGGL((resample_kernel<4, 1>), dim3(cdiv(total / 4, 256), B * C), dim3(256), 0, (hipStream_t)stream, in,
-                           in_bs, in_cs, out, out_bs, out_cs, C, F, T, mode, alpha, beta, tsh);
+                           in_bs, in_cs, out, out_bs, out_cs, C, F, T, mode, alpha, beta, tsh, res, res_bs, res_cs);
     else if (v4)
         hipLaunchKernelGGL((resample_kernel<4, 0>), dim3(cdiv(total / 4, 256), B * C), dim3(256), 0, (hipStream_t)stream, in,
-                           in_bs, in_cs, out, out_bs, out_cs, C, F, T, mode, alpha, beta, tsh);
+                           in_bs, in_cs, out, out_bs, out_cs, C, F, T, mode, alpha, beta, tsh, res, res_bs, res_cs);
     else
         hipLaunchKernelGGL((resample_kernel<1, 0>), dim3(cdiv(total, 256), B * C), dim3(256), 0, (hipStream_t)stream, in,
-                           in_bs, in_cs, out, out_bs, out_cs, C, F, T, mode, alpha, beta, tsh);
+                           in_bs, in_cs, out, out_bs, out_cs, C, F, T, mode, alpha, beta, tsh, res, res_bs, res_cs);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
+}
+
+extern "C" int babe_resample(const float* in, long in_bs, long in_cs, float* out, long out_bs, long out_cs, int B,
+                             int C, int F, int T, int mode, float alpha, float beta, void* stream) {
+    return resample_launch(in, in_bs, in_cs, out, out_bs, out_cs, nullptr, 0, 0, B, C, F, T, mode, alpha, beta, stream);
+}
+
+extern "C" int babe_resample_res(const float* in, long in_bs, long in_cs, const float* res, long res_bs, long res_cs, float* out,
+                                 long out_bs, long out_cs, int B, int C, int F, int T, int mode, float alpha, float beta,
+                                 void* stream) {
+    BABE_CHECK_ARG(res, "resample_res: null res");
+    return resample_launch(in, in_bs, in_cs, out, out_bs, out_cs, res, res_bs, res_cs, B, C, F, T, mode, alpha, beta, stream);
 }

@@ -315,15 +315,11 @@ class UnetEngine:
         for i in reversed(range(n)):
             Fi = bpo * (i + 1)
             if i == n - 1:
-                gHi = self.buf(B, Ns[i], Fi, Ts[i])
-                ops.axpby(gH[i], gHi)
-                ops.axpby(gXm, gHi, alpha=RS2, beta=1.0)
+                gHi = ops.axpby2(gH[i], gXm, self.buf(B, Ns[i], Fi, Ts[i]), 1.0, RS2)
                 gpyr = ops.conv2d(gXm, self.pyr_conv[i], self.buf(B, 2, Fi, Ts[i]), transpose=True, alpha=RS2)
             else:
                 # P_i = (down(H_i) + pconv_i(pyr_i)) * rs2 lives in XC_{i+1}[:, :, bpo:, :]
-                gHi = self.buf(B, Ns[i], Fi, Ts[i])
-                ops.axpby(gH[i], gHi)
-                ops.resample(gP, gHi, 2, alpha=RS2, beta=1.0)
+                gHi = ops.resample(gP, self.buf(B, Ns[i], Fi, Ts[i]), 2, alpha=RS2, beta=1.0, res=gH[i])   # g_skip + rs2 down^T(g_P), one pass
                 gpyr = self.buf(B, 2, Fi, Ts[i] // 2)
                 ops.conv2d(gP, self.pyr_conv[i], gpyr, transpose=True, alpha=RS2,
                            res=gpyr_next if gpyr_next is not None else None, rbeta=1.0 if gpyr_next is not None else 0.0)

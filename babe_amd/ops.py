@@ -300,14 +300,26 @@ def gn_bwd(x, da, gy, scale, stats, gx, rbeta, G=8, eps=1e-7):
     return gx
 
 
-def resample(x, out, mode, alpha=1.0, beta=0.0):
-    """mode 0 down, 1 up, 2 down^T, 3 up^T. T argument is the forward op's input length."""
+AXPBY2 = os.environ.get("BABE_AXPBY2", "1") != "0"          # 0: the two-pass forms of the merged element-wise passes (A/B switch)
+
+
+def resample(x, out, mode, alpha=1.0, beta=0.0, res=None):
+    """mode 0 down, 1 up, 2 down^T, 3 up^T. T argument is the forward op's input length.
+    out = alpha*R(x) + beta*out, or with res: out = alpha*R(x) + beta*res (one pass; unaligned views: copy, then accumulate)."""
     B, Cc, F, Tin = x.shape
     T = {0: Tin, 1: Tin, 2: Tin * 2, 3: Tin // 2}[mode]
     Tout = {0: T // 2, 1: 2 * T, 2: T, 3: T}[mode]
     assert out.shape == (B, Cc, F, Tout), (out.shape, (B, Cc, F, Tout))
     xp, xbs, xcs = _view(x)
     op, obs, ocs = _view(out)
+    if res is not None:
+        assert res.shape == out.shape
+        rp, rbs, rcs = _view(res)
+        if AXPBY2 and all(v % 4 == 0 for v in (rbs, rcs, obs, ocs)) and res.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0:
+            check(lib().babe_resample_res(xp, xbs, xcs, rp, rbs, rcs, op, obs, ocs, B, Cc, F, T, mode, alpha, beta, stream()),
+                  "resample_res")
+            return out
+        axpby(res, out)
     check(lib().babe_resample(xp, xbs, xcs, op, obs, ocs, B, Cc, F, T, mode, alpha, beta, stream()), "resample")
     return out
 
@@ -319,9 +331,6 @@ def axpby(x, out, alpha=1.0, beta=0.0):
     op, obs, ocs = _view(out)
     check(lib().babe_axpby4d(xp, xbs, xcs, op, obs, ocs, B, Cc, F, T, alpha, beta, stream()), "axpby4d")
     return out
-
-
-AXPBY2 = os.environ.get("BABE_AXPBY2", "1") != "0"          # 0: the two-pass form (A/B switch)
 
 
 def axpby2(x, y, out, alpha, beta):

@@ -147,6 +147,10 @@ int babe_gn_bwd_apply(const float* x, const float* da, const float* gy, const fl
  * T = time length of the INPUT of the forward op (for the adjoints: of the forward op's input too). */
 int babe_resample(const float* in, long in_bs, long in_cs, float* out, long out_bs, long out_cs,
                   int B, int C, int F, int T, int mode, float alpha, float beta, void* stream);
+/* out = alpha*resample(in) + beta*res with res a separate tensor of out's shape (16-byte aligned views): the encoder VJP's
+ * g_H = g_skip + rs2 * down^T(g_P) (cqtdiff+.py:776-794 backwards) without first copying g_skip into out */
+int babe_resample_res(const float* in, long in_bs, long in_cs, const float* res, long res_bs, long res_cs, float* out,
+                      long out_bs, long out_cs, int B, int C, int F, int T, int mode, float alpha, float beta, void* stream);
 
 /* ---- strided copy / axpby: out = alpha*in + beta*out on [B][C][F][T] views (torch.cat / slicing /
  * (a+b)/sqrt2 residual merges, cqtdiff+.py:769-774,794,814-822) */

@@ -339,6 +339,24 @@ def test_resample_fwd_and_adjoint(ops, T):
     assert float((big[:, :, :4, :] - 1).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode,T", [(2, 64), (2, 1024), (3, 64), (0, 256), (1, 64)])
+def test_resample_with_a_separate_residual_is_copy_then_accumulate_bit_for_bit(ops, mode, T):
+    """babe_resample_res: out = alpha R(x) + beta res in one pass == copy res -> out, then out = alpha R(x) + beta out; res a
+    channel-slice view (the encoder VJP's g_skip = gcat[:, N:]), out dense."""
+    g = torch.Generator().manual_seed(100 * mode + T)
+    Tin = {0: T, 1: T, 2: T // 2, 3: 2 * T}[mode]
+    To = {0: T // 2, 1: 2 * T, 2: T, 3: T}[mode]
+    x = torch.randn(2, 4, 6, Tin, generator=g).cuda()
+    cat = torch.randn(2, 8, 6, To, generator=g).cuda()
+    res = cat[:, 4:]
+    rs2 = 1.0 / math.sqrt(2.0)
+    o1 = torch.empty(2, 4, 6, To, device="cuda")
+    ops.axpby(res, o1)
+    ops.resample(x, o1, mode, alpha=rs2, beta=1.0)
+    o2 = ops.resample(x, torch.empty(2, 4, 6, To, device="cuda"), mode, alpha=rs2, beta=1.0, res=res)
+    assert torch.equal(o1, o2)
+
+
 def test_axpby_linear_rff(ops):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 3, 8, 40, generator=g)
