@@ -157,7 +157,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
     MAX_LANES = int(os.environ.get("BABE_UNET_STREAMS", "2"))
 
     def _get_lanes(self, B):
-        n = min(B, self.MAX_LANES) if self.concurrent_lanes_ok else 1      # (bf16: one stream unless BABE_BF16_LANES=1)
+        n = min(B, self.MAX_LANES) if self.concurrent_lanes_ok else 1      # (bf16: one stream if BABE_BF16_LANES=0)
         if n <= 1:
             return None
         if getattr(self, "_lanes", None) is None or len(self._lanes) != n:
@@ -196,15 +196,19 @@ class Unet_CQT_oct_with_attention(nn.Module):
 
     # ---------------------------------------------------------------- raw (no autograd) interface
     supports_lanes = True
-    # precision='bf16': ONE stream by default.  Round 3 found that kernels containing packed-fp32 instructions return wrong sums
-    # when they run beside conv_bf16p (v_mfma_f32_32x32x16_bf16) on another stream.  This library is built without any packed-fp32
-    # instruction (babe_amd/build.py; tests/test_no_packed_fp32.py) and its two-lane soak is clean, but the root cause is not
-    # identified and kernels this library does not build (ATen copies / RNG, RCCL, a caller's own kernels) still
-    # contain such instructions and may run on other streams - a recurrence would be silent numerical corruption.  Two bf16
-    # lanes are therefore opt-in: BABE_BF16_LANES=1 (3.18 -> 3.68 audio-sec/s on the benchmark, round 3).  fp32 is unaffected.
+    # precision='bf16' and clip lanes.  Round 3 found that kernels containing packed-fp32 instructions returned wrong sums when they
+    # ran beside conv_bf16p on another stream; round 4 reduced it to one instruction form (tools/pk_opsel_min.hip):
+    # v_pk_{mul,add,fma}_f32 with op_sel:[0,1] reads the HIGH word of its second source as 0 while another kernel's waves execute
+    # bf16 MFMA on the same CU.  What may run beside the bf16 conv in the lane loop is therefore checked, not assumed:
+    #   * this library: built without packed fp32; tests/test_no_packed_fp32.py rejects any v_pk_*_f32 and any op_sel modifier;
+    #   * PyTorch kernels launched inside the lane loop: copies and fills only (profiles/r04_bench_bf16_kernel_stats.csv lists
+    #     every kernel of a run) - no fp32 arithmetic, hence no such instruction; the sampler draws its noise on the host
+    #     (noise_device='cpu', the reference's behaviour) BEFORE the lanes fork, and the RCCL gather runs after they join.
+    # With the cause known the round-3 precaution (one stream) is no longer the default; BABE_BF16_LANES=0 restores it (a host
+    # application that runs its OWN hipcc-default kernels on other streams beside this network should set it).
     @property
     def concurrent_lanes_ok(self):
-        return self.precision != "bf16" or os.environ.get("BABE_BF16_LANES", "0") == "1"
+        return self.precision != "bf16" or os.environ.get("BABE_BF16_LANES", "1") != "0"
 
     def lane_engine(self, lane):
         """Engine state number `lane` (saved activations + scratch of its own over the shared packed weights): a caller that

@@ -226,13 +226,15 @@ def rms_err(a, b):
 def test_full_width_bf16_sampler_B4_per_clip_vs_fp32_reference_runs(monkeypatch):
     """configs[2]'s arithmetic on the sampler: four clips (the two golden clips, twice) as one per-clip bf16 batch, each
     row against the imported reference's fp32 B = 1 run.  Stated bar for plain bf16: RMS error < 5e-3 (signal RMS 0.1).
-    bf16 networks run on ONE stream by default (round 4: the cause of the round-3 co-residency corruption is not identified,
-    networks/cqtdiff_plus.py); this test opts in to two lanes (BABE_BF16_LANES=1) so that the two-lane path stays exercised."""
+    Two clip lanes (the default again since round 4 identified the co-residency corruption's cause, networks/cqtdiff_plus.py);
+    BABE_BF16_LANES=0 is the one-stream opt-out."""
     s = load("sampler_full_46046.npz")
     L, T = int(s["L"]), int(s["T"])
     net = full_net(L, "bf16")
-    assert not net.concurrent_lanes_ok                       # the default
-    monkeypatch.setenv("BABE_BF16_LANES", "1")
+    monkeypatch.setenv("BABE_BF16_LANES", "0")
+    assert not net.concurrent_lanes_ok                       # the opt-out
+    monkeypatch.delenv("BABE_BF16_LANES")
+    assert net.concurrent_lanes_ok                           # the default
     smp = _full_sampler(net, s)
     y = torch.cat([s["y0"], s["y1"], s["y0"], s["y1"]], 0).cuda()
     noises = [torch.cat([s["noises0"][i:i + 1], s["noises1"][i:i + 1]] * 2, 0) for i in range(T + 1)]

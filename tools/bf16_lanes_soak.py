@@ -4,7 +4,6 @@ bit-identical and every clip within the bf16 bar of the fp32 reference golden.""
 import os, sys, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
-os.environ["BABE_BF16_LANES"] = "1"
 import test_gpu_unet_full as tf
 s = tf.load("sampler_full_46046.npz")
 L, T = int(s["L"]), int(s["T"])
