@@ -156,6 +156,14 @@ __global__ __launch_bounds__(256) void axpby2_4d_kernel(const float* __restrict_
     }
 }
 
+// out[b][c][0 .. n) = value over [B][C] planes of n = F*T contiguous floats (zeroing the frequency sub-view a gradient is
+// accumulated into: unet_engine.py's gR[:, :, :bpo, :].zero_()).  grid: (blocks, B*C)
+__global__ __launch_bounds__(256) void fill4d_kernel(float* __restrict__ out, long out_bs, long out_cs, int C, long n, float value) {
+    const int b = blockIdx.y / C, c = blockIdx.y % C;
+    float* y = out + (long)b * out_bs + (long)c * out_cs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = value;
+}
+
 // one wave per output row j, all batches
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ out, int B,
@@ -225,6 +233,16 @@ extern "C" int babe_axpby2_4d(const float* x, long x_bs, long x_cs, const float*
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(axpby2_4d_kernel, dim3(bx, B * C), dim3(256), 0, (hipStream_t)stream, x, x_bs, x_cs, y, y_bs, y_cs, out, out_bs,
                        out_cs, C, n, alpha, beta);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_fill4d(float* out, long out_bs, long out_cs, int B, int C, int F, int T, float value, void* stream) {
+    BABE_CHECK_ARG(out && B > 0 && C > 0 && F > 0 && T > 0 && (long)B * C <= 65535, "fill4d: bad arguments");
+    const long n = (long)F * T;
+    int bx = cdiv(n, 1024);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(fill4d_kernel, dim3(bx, B * C), dim3(256), 0, (hipStream_t)stream, out, out_bs, out_cs, C, n, value);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

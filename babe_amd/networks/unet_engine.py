@@ -12,6 +12,7 @@ Each dilation layer keeps exactly one tensor (its input) for the VJP; GroupNorm 
 GELU are recomputed in the backward kernels.
 """
 import math
+import os
 
 import torch
 
@@ -19,6 +20,8 @@ from .. import ops
 from .._lib import bump_alloc_generation
 
 RS2 = 1.0 / math.sqrt(2.0)
+# the library-side sequencer (csrc/unet_engine.hip): one C call per direction.  BABE_UNET_C=1 enables it (fp32 networks).
+USE_C = os.environ.get("BABE_UNET_C", "0") == "1"
 
 
 class _Block:
@@ -98,6 +101,11 @@ class UnetEngine:
         import copy
         c = copy.copy(self)
         c._scratch = {}
+        c.__dict__.pop("_cunet", None)                   # own state + workspace over the SAME plan
+        if self.__dict__.get("_cunet") is not None:
+            c._cunet_parent = self._cunet
+        elif USE_C and self.precision == "f32":
+            c._cunet_parent = self._c_engine()
         cp = lambda blks: [copy.copy(b) for b in blks]
         c.init_blk, c.main_blk, c.up_out, c.up_blk = cp(self.init_blk), cp(self.main_blk), cp(self.up_out), cp(self.up_blk)
         c.mid_blk, c.mid_out = copy.copy(self.mid_blk), copy.copy(self.mid_out)
@@ -222,8 +230,26 @@ class UnetEngine:
         return g_in
 
     # ------------------------------------------------------------------ forward
+    def _c_engine(self):
+        """The library-side sequencer for this engine STATE (networks/unet_c.py), or None: fp32 only, BABE_UNET_C=0 switches it
+        off, the measurement hook's per-launch events work with either."""
+        if not USE_C or self.precision != "f32":
+            return None
+        cu = self.__dict__.get("_cunet")
+        if cu is None:
+            from .unet_c import CUnet
+            parent = self.__dict__.get("_cunet_parent")
+            cu = parent.clone(self) if parent is not None else CUnet(self)
+            self._cunet = cu
+        return cu
+
     def forward(self, C_list, film):
         """C_list[j]: planar [B,2,bpo,T_j], index 0 = lowest octave. Returns same structure."""
+        cu = self._c_engine()
+        if cu is not None:
+            self._c_fwd = True
+            return cu.fwd([c.contiguous() for c in C_list], film)
+        self._c_fwd = False
         n, bpo, Ns = self.nocts, self.bpo, self.Ns
         B = C_list[0].shape[0]
         Ts = [C_list[n - 1 - i].shape[-1] for i in range(n)]      # level i time length
@@ -278,6 +304,8 @@ class UnetEngine:
     # ------------------------------------------------------------------ input-VJP
     def vjp(self, gouts):
         """gouts[i]: gradient w.r.t. outs[i] (index 0 = lowest octave). Returns gradients w.r.t. C_list."""
+        if getattr(self, "_c_fwd", False):
+            return self._c_engine().vjp([g.contiguous() for g in gouts])
         n, bpo, Ns, Ts, B = self.nocts, self.bpo, self.Ns, self.Ts, self.B
         gH = [None] * n
         gX_prev = gXO_prev = None          # gradients w.r.t. X_{j-1}, XO_{j-1} (outputs of the up-samplers)

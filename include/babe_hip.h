@@ -152,10 +152,44 @@ int babe_resample(const float* in, long in_bs, long in_cs, float* out, long out_
 int babe_resample_res(const float* in, long in_bs, long in_cs, const float* res, long res_bs, long res_cs, float* out,
                       long out_bs, long out_cs, int B, int C, int F, int T, int mode, float alpha, float beta, void* stream);
 
+/* ---- the whole UNet body from one call: networks/cqtdiff+.py:746-839 (forward), ResnetBlock :452-493, and its input-VJP
+ * (the autograd pass of testing/blind_bwe_sampler.py:120).  csrc/unet_engine.hip sequences the op-level functions of this header
+ * exactly as babe_amd/networks/unet_engine.py does (bit-identical results); fp32 convs.  All device memory is the caller's. */
+typedef struct {                       /* every image babe_amd/ops.py::PackedConv builds for one Conv2d; NULL = not packed */
+    int Cout, Cin, KH, KW, nt, splits; /* Cout == 0: the layer does not exist; splits: 0 fp32, 1 bf16, 2 bf16x3 */
+    const void *fwd, *bwd;             /* babe_conv_pack_weights_nt (fp32) or babe_conv_pack_weights_bf16 images, transpose_flip 0 / 1 */
+    const float *fwd_wino, *bwd_wino, *fwd_wino4, *bwd_wino4, *fwd_wino45, *bwd_wino45;
+    const float* w_raw;                /* reference layout, for babe_conv2d_fewco (<= 4 channels on one side) */
+} babe_packed_conv;
+/* conv with the kernel chosen by the library; a->w_packed, Cin, Cout, KH, KW are filled in from pc / transpose */
+int babe_conv2d_auto(babe_conv_args* a, const babe_packed_conv* pc, int transpose, void* stream);
+typedef struct {                       /* one ResnetBlock */
+    int N, nd, k53;                    /* channels of the dilated stack, dilation layers (dilation 2^d when k53), (5,3) kernels? */
+    babe_packed_conv proj_in, res_conv, proj_out, H[8];
+    const float* gamma[8];             /* BiasFreeGroupNorm gamma of layer d, [N] */
+    int film_aff[8], film_gate[8];     /* offsets of layer d's affine / gate vectors in the FiLM row */
+} babe_unet_block;
+typedef struct {
+    int nocts, bpo;                    /* octaves (7), bins per octave (64) */
+    int Ns[8];
+    babe_unet_block init_blk[8], main_blk[8], up_out[8], up_blk[8], mid_blk, mid_out;
+    babe_packed_conv pyr_conv[8];
+} babe_unet_plan_desc;
+void* babe_unet_plan_create(const babe_unet_plan_desc* desc);      /* copies the descriptor (pointers stay the caller's) */
+void babe_unet_plan_destroy(void* plan);
+void* babe_unet_state_create(void);                                 /* one evaluation's bookkeeping; one per concurrent stream */
+void babe_unet_state_destroy(void* state);
+long babe_unet_workspace_bytes(const void* plan, int B, const int* T_oct);
+int babe_unet_fwd(const void* plan, void* state, const float* const* C_in, const float* film, long film_bs, int B,
+                  const int* T_oct, void* workspace, long workspace_bytes, float* const* outs, void* stream);
+int babe_unet_vjp(const void* plan, void* state, const float* const* gouts, float* const* gC, void* stream);
+
 /* ---- strided copy / axpby: out = alpha*in + beta*out on [B][C][F][T] views (torch.cat / slicing /
  * (a+b)/sqrt2 residual merges, cqtdiff+.py:769-774,794,814-822) */
 int babe_axpby4d(const float* in, long in_bs, long in_cs, float* out, long out_bs, long out_cs,
                  int B, int C, int F, int T, float alpha, float beta, void* stream);
+/* out[b][c][:, :] = value on a [B][C][F][T] view */
+int babe_fill4d(float* out, long out_bs, long out_cs, int B, int C, int F, int T, float value, void* stream);
 /* out = alpha*x + beta*y in one pass (ResnetBlock's (x + h)/sqrt2 without res_conv, cqtdiff+.py:493); every view 16-byte aligned,
  * F*T % 4 == 0 */
 int babe_axpby2_4d(const float* x, long x_bs, long x_cs, const float* y, long y_bs, long y_cs, float* out, long out_bs,
