@@ -84,7 +84,10 @@ struct Ctx {
     int B() const { return S->B; }
     bool dry() const { return S->dry; }
     float* alloc(size_t nfloat) {
-        const size_t bytes = (nfloat * 4 + 255) & ~(size_t)255;
+        // (+ an odd number of 256-byte granules: tensor sizes here are large powers of two times small integers, and operands
+        // that start at multiples of the same power of two walk the HBM channels in lockstep)
+        static const size_t skew = [] { const char* e = getenv("BABE_UNET_SKEW"); return e ? (size_t)atol(e) : (size_t)4352; }();
+        const size_t bytes = ((nfloat * 4 + 255) & ~(size_t)255) + skew;
         float* p = S->ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(S->ws) + S->off) : nullptr;
         S->off += bytes;
         if (S->off > S->high) S->high = S->off;
@@ -100,6 +103,10 @@ struct Ctx {
         v.C = C; v.F = F; v.T = T; v.cs = (long)F * T; v.bs = (long)C * F * T;
         return v;
     }
+    // stack discipline for the VJP's temporaries: what a level needs only while it runs is carved after a mark and given back, so
+    // the next level reuses the same (cache-warm) bytes - what the caching allocator did for the Python-sequenced engine
+    size_t mark() const { return S->off; }
+    void release(size_t m) { S->off = m; }
     float* scratch_a(size_t n) {
         if (n > S->scr_a_n) { S->scr_a = alloc(n); S->scr_a_n = n; }
         return S->scr_a;
@@ -326,6 +333,10 @@ struct Ctx {
             const int i = n - 1 - j;
             const int Fj = bpo * (j + 1);
             const int Nout = Ns[j > 0 ? j - 1 : 0];
+            // (what outlives the level first: the next level reads gXOn / gcat[:, :N], the encoder VJP gcat[:, N:])
+            View gXOn = buf(2, Fj, Ts[j]);
+            View gcat = buf(2 * Ns[j], Fj, Ts[j]);
+            const size_t lvl = mark();
             View gXOp = buf(2, Fj, Ts[j]);
             View go; go.p = const_cast<float*>(gouts[i]); go.C = 2; go.F = bpo; go.T = Ts[j]; go.cs = (long)bpo * Ts[j]; go.bs = 2 * go.cs;
             axpby(go, sub_f(gXOp, 0, bpo));
@@ -340,13 +351,12 @@ struct Ctx {
             View gO = buf(2, Fj, Ts[j]);
             axpby(gXOp, gO, RS2);
             block_vjp(P->up_out[i], S->saved[2][i], gO, gR, accumulate, true);
-            View gXOn = buf(2, Fj, Ts[j]);
             axpby(gXOp, gXOn, RS2);
             gXO_prev = gXOn;
-            View gcat = buf(2 * Ns[j], Fj, Ts[j]);
             block_vjp(P->up_blk[i], S->saved[3][i], gR, gcat, false, true);
             gX_prev = sub_c(gcat, 0, Ns[j]);
             gH[j] = sub_c(gcat, Ns[j], Ns[j]);
+            release(lvl);
         }
         View gM = buf(Ns[n - 1], bpo * n, Ts[n - 1]);
         axpby(gX_prev, gM);
@@ -357,22 +367,25 @@ struct Ctx {
         bool have_next = false;
         for (int i = n - 1; i >= 0; --i) {
             const int Fi = bpo * (i + 1);
+            const int Nin = Ns[i > 0 ? i - 1 : 0];
+            // (read by the next level: gXC[:, :, bpo:] = g_P, the pyramid gradient; the level's own temporaries come after the mark)
+            View gXC = buf(Nin, Fi, Ts[i]);
+            View gpyr = i == n - 1 ? buf(2, Fi, Ts[i]) : buf(2, Fi, Ts[i] / 2);
+            View nx;
+            if (i > 0 && i < n - 1) nx = buf(2, Fi - bpo, Ts[i]);
+            const size_t lvl = mark();
             View gHi = buf(Ns[i], Fi, Ts[i]);
-            View gpyr;
             if (i == n - 1) {
                 axpby2(gH[i], gXm, gHi, 1.f, RS2);
-                gpyr = buf(2, Fi, Ts[i]);
                 conv(gXm, P->pyr_conv[i], gpyr, 1, true, nullptr, nullptr, nullptr, nullptr, RS2, 0.f);
             } else {
                 resample(gP, gHi, 2, RS2, 1.f, &gH[i]);
-                gpyr = buf(2, Fi, Ts[i] / 2);
                 conv(gP, P->pyr_conv[i], gpyr, 1, true, nullptr, have_next ? &gpyr_next : nullptr, nullptr, nullptr, RS2, have_next ? 1.f : 0.f);
             }
-            const int Nin = Ns[i > 0 ? i - 1 : 0];
-            View gXC = buf(Nin, Fi, Ts[i]);
             block_vjp(P->main_blk[i], S->saved[1][i], gHi, gXC, false, true);
             View gCi; gCi.p = gC[n - 1 - i]; gCi.C = 2; gCi.F = bpo; gCi.T = Ts[i]; gCi.cs = (long)bpo * Ts[i]; gCi.bs = 2 * gCi.cs;
             block_vjp(P->init_blk[i], S->saved[0][i], sub_f(gXC, 0, bpo), gCi, false, false);
+            release(lvl);
             if (i > 0) gP = sub_f(gXC, bpo, Fi - bpo);
             if (i == n - 1) {
                 axpby(sub_f(gpyr, 0, bpo), gCi, 1.f, 1.f);
@@ -380,7 +393,6 @@ struct Ctx {
                 have_next = true;
             } else if (i > 0) {
                 resample(sub_f(gpyr, 0, bpo), gCi, 2, 1.f, 1.f);
-                View nx = buf(2, Fi - bpo, Ts[i]);
                 resample(sub_f(gpyr, bpo, Fi - bpo), nx, 2);
                 gpyr_next = nx;
                 have_next = true;
