@@ -61,6 +61,7 @@ _SIGS = {
     "babe_conv2d_bf16_units": [C.POINTER(ConvArgs), _P, _P],
     "babe_gn_bwd_partial": [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "babe_gn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _L, _I, _F, _P],
+    "babe_gn_bwd_apply_merge": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _L, _I, _F, _P, _P, _F, _F],
     "babe_resample": [_P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P],
     "babe_resample_res": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P],
     "babe_axpby4d": [_P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _F, _F, _P],

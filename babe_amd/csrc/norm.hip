@@ -374,7 +374,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ stats,
                                                            const double* __restrict__ part, float* __restrict__ gx,
-                                                           float rbeta, int C, int G, long hw, int S, float eps) {
+                                                           float rbeta, int C, int G, long hw, int S, float eps,
+                                                           const float* __restrict__ acc, float ca, float cb) {
     const int c = blockIdx.y, b = blockIdx.z;
     const int cg = C / G;
     const int g = c / cg;
@@ -419,6 +420,18 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
             o.y += rbeta * gv.y;
             o.z += rbeta * gv.z;
             o.w += rbeta * gv.w;
+        }
+        if (acc) {
+            // merged block tail (babe_gn_bwd_apply_merge): out = ca*acc + cb*gx instead of storing gx and running axpby2 over it;
+            // rounded as the two-pass form: fl(fl(ca acc) + fl(cb gx))
+#pragma clang fp contract(off)
+            const float4 av = reinterpret_cast<const float4*>(acc + base)[i];
+            const float px = ca * av.x, py = ca * av.y, pz = ca * av.z, pw = ca * av.w;
+            const float qx = cb * o.x, qy = cb * o.y, qz = cb * o.z, qw = cb * o.w;
+            o.x = px + qx;
+            o.y = py + qy;
+            o.z = pz + qz;
+            o.w = pw + qw;
         }
         o4[i] = o;
     }
@@ -518,17 +531,32 @@ extern "C" int babe_gn_bwd_partial(const float* x, const float* da, const float*
     return BABE_OK;
 }
 
-extern "C" int babe_gn_bwd_apply(const float* x, const float* da, const float* gy, const float* scale,
+static int gn_bwd_apply_launch(const float* acc, float ca, float cb, const float* x, const float* da, const float* gy, const float* scale,
                                  const float* stats, const double* part, float* gx, float rbeta, int B, int C, int G,
                                  long hw, int S, float eps, void* stream) {
     BABE_CHECK_ARG(x && da && scale && stats && part && gx, "gn_bwd_apply: null pointer");
     BABE_CHECK_ARG(hw % 4 == 0 && C % G == 0, "gn_bwd_apply: hw=%ld C=%d G=%d unsupported", hw, C, G);
-    BabeProfScope prof(BABE_SLOT_GN_BWD_APPLY, (gy ? 16.0 : 12.0) * B * C * (double)hw, 0, 0, stream);
+    BabeProfScope prof(BABE_SLOT_GN_BWD_APPLY, ((gy ? 16.0 : 12.0) + (acc ? 4.0 : 0.0)) * B * C * (double)hw, 0, 0, stream);
     int bx = cdiv(hw / 4, 256 * 4);
     if (bx < 1) bx = 1;
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, da, gy, scale, stats,
-                       part, gx, rbeta, C, G, hw, S, eps);
+                       part, gx, rbeta, C, G, hw, S, eps, acc, ca, cb);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }
+
+extern "C" int babe_gn_bwd_apply(const float* x, const float* da, const float* gy, const float* scale,
+                                 const float* stats, const double* part, float* gx, float rbeta, int B, int C, int G,
+                                 long hw, int S, float eps, void* stream) {
+    return gn_bwd_apply_launch(nullptr, 0.f, 0.f, x, da, gy, scale, stats, part, gx, rbeta, B, C, G, hw, S, eps, stream);
+}
+
+/* the same pass with the block's tail merged in: out = ca*acc + cb*(the gx babe_gn_bwd_apply would store); acc: dense [B][C][hw] */
+extern "C" int babe_gn_bwd_apply_merge(const float* x, const float* da, const float* gy, const float* scale,
+                                 const float* stats, const double* part, float* gx, float rbeta, int B, int C, int G,
+                                 long hw, int S, float eps, void* stream, const float* acc, float ca, float cb) {
+    BABE_CHECK_ARG(acc && ((uintptr_t)acc & 15) == 0, "gn_bwd_apply_merge: acc must be a 16-byte aligned dense tensor");
+    return gn_bwd_apply_launch(acc, ca, cb, x, da, gy, scale, stats, part, gx, rbeta, B, C, G, hw, S, eps, stream);
+}
+

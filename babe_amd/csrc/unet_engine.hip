@@ -204,14 +204,18 @@ struct Ctx {
         else axpby2(z, x, out, RS2, RS2);
         return out;
     }
-    void gn_bwd(const Saved& sv, const View& da, const View& gy, const View& gx, float rbeta) {
+    void gn_bwd(const Saved& sv, const View& da, const View& gy, const View& gx, float rbeta, const View* acc = nullptr) {
         const View& z = sv.z;
         const long n = (long)(z.C / G_GROUPS) * z.F * z.T;
         const int Sp = splits(n);
         double* part = reinterpret_cast<double*>(alloc((size_t)B() * G_GROUPS * Sp * 2));
         if (dry() || err) return;
         ck(babe_gn_bwd_partial(z.p, da.p, sv.scale, part, B(), z.C, G_GROUPS, (long)z.F * z.T, Sp, st));
-        ck(babe_gn_bwd_apply(z.p, da.p, gy.p, sv.scale, sv.stats, part, gx.p, rbeta, B(), z.C, G_GROUPS, (long)z.F * z.T, Sp, GN_EPS, st));
+        if (acc)          // the block's tail merged in: gx = RS2*acc + RS2*(this layer's gradient)
+            ck(babe_gn_bwd_apply_merge(z.p, da.p, gy.p, sv.scale, sv.stats, part, gx.p, rbeta, B(), z.C, G_GROUPS, (long)z.F * z.T, Sp, GN_EPS, st,
+                                       acc->p, RS2, RS2));
+        else
+            ck(babe_gn_bwd_apply(z.p, da.p, gy.p, sv.scale, sv.stats, part, gx.p, rbeta, B(), z.C, G_GROUPS, (long)z.F * z.T, Sp, GN_EPS, st));
     }
     // g_in (+)= VJP of the block w.r.t. its (concatenated) input; consume: g_out is a dense buffer that may be overwritten
     View block_vjp(const babe_unet_block& blk, const Saved* saved, const View& g_out, const View& g_in, bool accumulate, bool consume) {
@@ -219,15 +223,22 @@ struct Ctx {
         const float beta = accumulate ? 1.f : 0.f;
         auto da_view = [&]() { View v; v.p = scratch_a((size_t)B() * N * Fq * T); v.C = N; v.F = Fq; v.T = T; v.cs = (long)Fq * T; v.bs = (long)N * Fq * T; return v; };
         if (!blk.res_conv.Cout && !blk.proj_out.Cout && !blk.proj_in.Cout && !accumulate && blk.nd > 0 && g_out.dense()) {
-            View gz = buf(N, Fq, T);
+            View gz;
+            if (blk.nd > 1) gz = buf(N, Fq, T);
             View da = da_view();
             View src = g_out;
+            const bool merged = g_in.dense() && al16(g_in) && al16(g_out);
             for (int d = blk.nd - 1; d >= 0; --d) {
                 conv(src, blk.H[d], da, blk.k53 ? (1 << d) : 1, true, nullptr, nullptr, saved[d].gate, nullptr, RS2, 0.f);
-                gn_bwd(saved[d], da, src, gz, RS2);
-                src = gz;
+                if (d == 0 && merged) {
+                    gn_bwd(saved[d], da, src, g_in, RS2, &g_out);
+                } else {
+                    if (!gz.p && !gz.C) gz = buf(N, Fq, T);
+                    gn_bwd(saved[d], da, src, gz, RS2);
+                    src = gz;
+                }
             }
-            axpby2(g_out, gz, g_in, RS2, RS2);
+            if (!merged) axpby2(g_out, gz, g_in, RS2, RS2);
             return g_in;
         }
         if (blk.res_conv.Cout) conv(g_out, blk.res_conv, g_in, 1, true, nullptr, accumulate ? &g_in : nullptr, nullptr, nullptr, RS2, beta);

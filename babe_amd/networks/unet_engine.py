@@ -22,6 +22,7 @@ from .._lib import bump_alloc_generation
 RS2 = 1.0 / math.sqrt(2.0)
 # the library-side sequencer (csrc/unet_engine.hip): one C call per direction.  BABE_UNET_C=1 enables it (fp32 networks).
 USE_C = os.environ.get("BABE_UNET_C", "0") == "1"
+MERGE_TAIL = os.environ.get("BABE_MERGE_TAIL", "1") != "0"      # 0: N -> N block VJP stores gz and merges with axpby2 (A/B switch)
 
 
 class _Block:
@@ -192,15 +193,23 @@ class UnetEngine:
             # c*gz are merged in ONE pass at the end (12 instead of 8 + 12 bytes per element).  For that g_out has to survive the
             # chain: the first layer's gn_bwd reads it as its residual input and writes into a buffer of its own (same traffic),
             # the later layers update that buffer in place.  Same arithmetic, same rounding as the two-pass form.
-            gz = self.buf(B, N, Fq, T)
+            gz = self.buf(B, N, Fq, T) if blk.nd > 1 else None
             da = self.scratch("a", B * N * Fq * T).view(B, N, Fq, T)
             src = g_out
+            merged = g_in.is_contiguous() and MERGE_TAIL
             for d in reversed(range(blk.nd)):
                 z, stats, scale, gate = blk.saved[d]
                 ops.conv2d(src, blk.H[d], da, dil=blk.dil(d), transpose=True, in_scale=gate, alpha=RS2)
-                ops.gn_bwd(z, da, src, scale, stats, gz, RS2)
-                src = gz
-            ops.axpby2(g_out, gz, g_in, RS2, RS2)
+                if d == 0 and merged:
+                    # the last layer's VJP pass writes g_in = RS2*g_out + RS2*gz itself (gz is never stored)
+                    ops.gn_bwd(z, da, src, scale, stats, g_in, RS2, merge=(g_out, RS2, RS2))
+                else:
+                    if gz is None:
+                        gz = self.buf(B, N, Fq, T)
+                    ops.gn_bwd(z, da, src, scale, stats, gz, RS2)
+                    src = gz
+            if not merged:
+                ops.axpby2(g_out, gz, g_in, RS2, RS2)
             blk.saved = None
             return g_in
         # residual path

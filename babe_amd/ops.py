@@ -286,8 +286,9 @@ def conv2d_units(au, pc, out, Cin, dil=1, res=None, oscale=None, alpha=1.0, rbet
     return out
 
 
-def gn_bwd(x, da, gy, scale, stats, gx, rbeta, G=8, eps=1e-7):
-    """gx = rbeta*gy + GN/FiLM/GELU input-VJP of da (gx may alias gy; da is only read)."""
+def gn_bwd(x, da, gy, scale, stats, gx, rbeta, G=8, eps=1e-7, merge=None):
+    """gx = rbeta*gy + GN/FiLM/GELU input-VJP of da (gx may alias gy; da is only read).
+    merge=(acc, ca, cb): gx = ca*acc + cb*(that result) in the same pass (a block's VJP tail, babe_gn_bwd_apply_merge)."""
     B, Cc, F, T = x.shape
     assert x.is_contiguous() and da.is_contiguous() and gx.is_contiguous() and (gy is None or gy.is_contiguous())
     n = (Cc // G) * F * T
@@ -295,6 +296,12 @@ def gn_bwd(x, da, gy, scale, stats, gx, rbeta, G=8, eps=1e-7):
     part = torch.empty(B * G * S, device=x.device, dtype=torch.float64)
     L = lib()
     check(L.babe_gn_bwd_partial(ptr(x), ptr(da), ptr(scale), ptr(part), B, Cc, G, F * T, S, stream()), "gn_bwd_partial")
+    if merge is not None:
+        acc, ca, cb = merge
+        assert acc.is_contiguous() and acc.shape == x.shape
+        check(L.babe_gn_bwd_apply_merge(ptr(x), ptr(da), ptr(gy), ptr(scale), ptr(stats), ptr(part), ptr(gx), rbeta, B, Cc, G,
+                                        F * T, S, eps, stream(), ptr(acc), ca, cb), "gn_bwd_apply_merge")
+        return gx
     check(L.babe_gn_bwd_apply(ptr(x), ptr(da), ptr(gy), ptr(scale), ptr(stats), ptr(part), ptr(gx), rbeta, B, Cc, G,
                               F * T, S, eps, stream()), "gn_bwd_apply")
     return gx

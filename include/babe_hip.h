@@ -141,6 +141,12 @@ int babe_gn_bwd_partial(const float* x, const float* da, const float* scale, dou
 int babe_gn_bwd_apply(const float* x, const float* da, const float* gy, const float* scale,
                       const float* stats, const double* part, float* gx, float rbeta,
                       int B, int C, int G, long hw, int S, float eps, void* stream);
+/* the same pass with a ResnetBlock's VJP tail merged in: gx_out = ca*acc + cb*(the gx babe_gn_bwd_apply would store) - the residual
+ * path's rs2*g_out plus the main path's rs2*gz of an N -> N block, without storing gz and re-reading it (acc dense, 16-byte aligned) */
+int babe_gn_bwd_apply_merge(const float* x, const float* da, const float* gy, const float* scale,
+                            const float* stats, const double* part, float* gx, float rbeta,
+                            int B, int C, int G, long hw, int S, float eps, void* stream,
+                            const float* acc, float ca, float cb);
 
 /* ---- UpDownResample ('cubic', reflect): cqtdiff+.py:549-580 (conv1d / conv_transpose1d with a
  * dense diagonal weight) as a depth-wise 8-tap polyphase FIR.  mode: 0 down, 1 up, 2 down^T, 3 up^T.

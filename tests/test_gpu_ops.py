@@ -374,6 +374,26 @@ def test_axpby_linear_rff(ops):
     assert float((ops.rff(cn.cuda(), fr.cuda()).cpu() - ref).abs().max()) < 2e-4
 
 
+def test_gn_bwd_with_merged_block_tail_equals_two_passes_bit_for_bit(ops):
+    """babe_gn_bwd_apply_merge: out = ca*acc + cb*gx in the GroupNorm-VJP pass itself == gn_bwd (gx stored) followed by
+    axpby2(acc, gx): the tail of an N -> N ResnetBlock's VJP (unet_engine.block_vjp)."""
+    g = torch.Generator().manual_seed(23)
+    rs2 = 1.0 / math.sqrt(2.0)
+    for (B, C, F, T) in [(2, 16, 12, 64), (1, 64, 40, 128)]:
+        x = torch.randn(B, C, F, T, generator=g).cuda()
+        gamma = (1 + 0.1 * torch.randn(C, generator=g)).cuda()
+        film = (0.2 * torch.randn(B, C, generator=g)).cuda()
+        a = torch.empty_like(x)
+        stats, scale = ops.gn_scale_gelu(x, gamma, film, a)
+        da = torch.randn(B, C, F, T, generator=g).cuda()
+        gy = torch.randn(B, C, F, T, generator=g).cuda()
+        acc = torch.randn(B, C, F, T, generator=g).cuda()
+        gx = ops.gn_bwd(x, da, gy, scale, stats, torch.empty_like(x), rs2)
+        want = ops.axpby2(acc, gx, torch.empty_like(x), rs2, rs2)
+        got = ops.gn_bwd(x, da, gy, scale, stats, torch.empty_like(x), rs2, merge=(acc, rs2, rs2))
+        assert torch.equal(want, got), (B, C, F, T)
+
+
 def test_axpby2_is_the_two_pass_residual_merge_bit_for_bit(ops):
     """babe_axpby2_4d (out = a x + b y in one pass, the (x + h)/sqrt2 merge of cqtdiff+.py:493) == axpby(x -> out, a) followed by
     axpby(y, out, b, 1), incl. a strided frequency sub-view as the destination and the unaligned fallback."""
