@@ -102,6 +102,9 @@ def lib():
         L.babe_prof_conv_slot.argtypes = [_I]
         L.babe_prof_read.argtypes = [_P, _P, _P, _P, _P]
         L.babe_prof_dispatch_counts.argtypes = [_P, _I]
+        L.babe_prof_timeline.restype = C.c_long
+        L.babe_prof_timeline.argtypes = [_P, _P, _P, _P, _P, C.c_long]
+        L.babe_prof_pending.restype = C.c_long
         _lib = L
     return _lib
 
@@ -151,6 +154,21 @@ def prof_read():
     check(L.babe_prof_read(ms, by, fl, ex, nl), "prof_read")
     return {name: dict(ms=ms[i], bytes=by[i], flops=fl[i], exec_flops=ex[i], launches=nl[i])
             for i, name in enumerate(prof_slot_names())}
+
+
+def prof_timeline():
+    """Per-launch records pending since the last prof_read() - call BEFORE it: dict of numpy arrays t0_ms, t1_ms (relative to
+    the first record), slot (index into prof_slot_names()), lane (stream index), flops.  Waits for the GPU."""
+    import numpy as np
+    L = lib()
+    n = int(L.babe_prof_pending())
+    t0, t1, fl = np.zeros(n), np.zeros(n), np.zeros(n)
+    sl, ln = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    as_p = lambda a: a.ctypes.data_as(C.c_void_p)
+    m = L.babe_prof_timeline(as_p(t0), as_p(t1), as_p(sl), as_p(ln), as_p(fl), n)
+    if m < 0:
+        raise BabeHipError(f"prof_timeline failed ({m}): {L.babe_last_error().decode()}")
+    return dict(t0_ms=t0[:m], t1_ms=t1[:m], slot=sl[:m], lane=ln[:m], flops=fl[:m])
 
 
 def dispatch_counts(reset=False):

@@ -42,7 +42,9 @@ __device__ __forceinline__ c11_i32x4 c11_rsrc(const void* p, unsigned bytes) {
 __device__ __forceinline__ void c11_dma16(c11_i32x4 rs, const float* lds_dst, unsigned voff) {
 #if __HIP_DEVICE_COMPILE__
     const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)LDS_PTR(lds_dst));
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(rs) : "memory");
+    // (m0 is clobbered: without saying so hipcc may keep a live value there across the statement - movrel indexing, readlane,
+    // a builtin LDS-DMA elsewhere in the kernel)
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(rs) : "memory", "m0");
 #endif
 }
 

@@ -1175,7 +1175,11 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(BABE_W45X_NU
     issue_isc(cA);
     pS = pA;
     X_FENCE0
-    asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)");        // the 9 weight DMAs landed (7 younger loads stay in flight)
+    // In flight here, oldest first: 9 weight DMAs (slots 0-2), then the 5 loads of super-slab 1 (4 rows + halo; the edge rows are
+    // issued in pass 2 only, which the prologue never reaches).  vmcnt(7) = everything but the 7 youngest: slot 0, slot 1 and the
+    // first chunk of slot 2 have landed - slot 0 is what the first operand read below needs; slots 1 and 2 are covered by the
+    // loop's own counted waits at g2 / g5 (13 resp. 11 younger operations by then).
+    asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)");
     __builtin_amdgcn_s_barrier();
 
     X_FENCE0

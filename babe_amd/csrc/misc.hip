@@ -18,7 +18,7 @@ extern "C" const char* babe_version(void) { return "babe_hip 0.1 (gfx950)"; }
 
 // ---- measurement hook (prof.h) ---------------------------------------------------------------------------------------
 namespace {
-struct ProfRec { hipEvent_t e0, e1; int slot; };
+struct ProfRec { hipEvent_t e0, e1; int slot; void* stream; double flops; };
 struct Prof {
     bool on = false;
     int conv_slot_override = -1;          // >= 0: conv launches are tallied there (the DFT stages of the CQT)
@@ -47,6 +47,8 @@ extern "C" void babe_prof_begin(int slot, double bytes, double flops, double exe
     }
     ProfRec& r = g_prof.rec[g_prof.used];
     r.slot = slot;
+    r.stream = stream;
+    r.flops = flops;
     (void)hipEventRecord(r.e0, (hipStream_t)stream);
     g_prof.bytes[slot] += bytes;
     g_prof.flops[slot] += flops;
@@ -97,6 +99,35 @@ extern "C" int babe_prof_read(double* ms, double* bytes, double* flops, double* 
     g_prof.used = 0;
     return BABE_OK;
 }
+/* Timeline of the pending records (call BEFORE babe_prof_read, which resets): for record i, t0_ms[i] / t1_ms[i] = GPU time of
+ * its two events relative to the first record's start event (events of different streams share the device clock), slot[i],
+ * lane[i] = index of its stream in order of first appearance, flops[i] = the algorithmic flops it was tallied with.  An
+ * interval is [the stream reached the launch, the kernel finished]; lanes that run concurrently are NOT serialised (a
+ * rocprofv3 kernel trace serialises them).  Returns the number of records written (<= cap), or a negative error. */
+extern "C" long babe_prof_timeline(double* t0_ms, double* t1_ms, int* slot, int* lane, double* flops, long cap) {
+    std::vector<void*> streams;
+    long n = 0;
+    for (size_t i = 0; i < g_prof.used && n < cap; ++i, ++n) {
+        ProfRec& r = g_prof.rec[i];
+        if (hipEventSynchronize(r.e1) != hipSuccess) {
+            babe_set_error("prof_timeline: hipEventSynchronize failed");
+            return BABE_ERR_HIP;
+        }
+        float a = 0, b = 0;
+        (void)hipEventElapsedTime(&a, g_prof.rec[0].e0, r.e0);
+        (void)hipEventElapsedTime(&b, g_prof.rec[0].e0, r.e1);
+        size_t k = 0;
+        while (k < streams.size() && streams[k] != r.stream) ++k;
+        if (k == streams.size()) streams.push_back(r.stream);
+        if (t0_ms) t0_ms[n] = a;
+        if (t1_ms) t1_ms[n] = b;
+        if (slot) slot[n] = r.slot;
+        if (lane) lane[n] = (int)k;
+        if (flops) flops[n] = r.flops;
+    }
+    return n;
+}
+extern "C" long babe_prof_pending(void) { return (long)g_prof.used; }
 /* always-on launch counters per slot (which kernel a conv call really dispatched to); reset != 0 clears them */
 extern "C" int babe_prof_dispatch_counts(long* counts, int reset) {
     for (int i = 0; i < BABE_NSLOTS; ++i) {

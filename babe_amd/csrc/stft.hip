@@ -777,8 +777,8 @@ extern "C" int babe_filter_fit(const double* stats, float* params, int* n_iter, 
     BABE_CHECK_ARG(stats && params && cfg && P > 0 && K > 0 && K <= KMAX && nbins > 1, "filter_fit: bad arguments");
     BabeProfScope prof(BABE_SLOT_FILTER_FIT, 24.0 * P * (double)nbins, 0, 0, stream);
     const float df = fs / (float)nfft;
-    static const char* ov = getenv("BABE_FIT_FAST");
-    if (nbins <= FIT_NT * FIT_NB && !(ov && ov[0] == '0')) {
+    BABE_CHECK_ARG(cfg->kernel == 0 || cfg->kernel == 1, "filter_fit: cfg.kernel %d (0 fast, 1 reference-order)", cfg->kernel);
+    if (nbins <= FIT_NT * FIT_NB && cfg->kernel == 0) {
 #define FIT_CASE(k)                                                                                                      \
     case k:                                                                                                              \
         hipLaunchKernelGGL(filter_fit_fast_kernel<k>, dim3(P), dim3(FIT_NT), 0, (hipStream_t)stream, stats, params, n_iter, \

@@ -86,7 +86,14 @@ struct Ctx {
     float* alloc(size_t nfloat) {
         // (+ an odd number of 256-byte granules: tensor sizes here are large powers of two times small integers, and operands
         // that start at multiples of the same power of two walk the HBM channels in lockstep)
-        static const size_t skew = [] { const char* e = getenv("BABE_UNET_SKEW"); return e ? (size_t)atol(e) : (size_t)4352; }();
+        // (BABE_UNET_SKEW overrides the 4352 bytes; rounded to a multiple of 256 so that every carved buffer keeps the alignment the
+        // float4 / LDS-DMA kernels need, negative values read as 0)
+        static const size_t skew = [] {
+            const char* e = getenv("BABE_UNET_SKEW");
+            long v = e ? atol(e) : 4352L;
+            if (v < 0) v = 0;
+            return (size_t)((v + 255) / 256 * 256);
+        }();
         const size_t bytes = ((nfloat * 4 + 255) & ~(size_t)255) + skew;
         float* p = S->ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(S->ws) + S->off) : nullptr;
         S->off += bytes;
@@ -414,18 +421,40 @@ struct Ctx {
     }
 };
 
+// A descriptor arrives from ANY C-ABI host: everything the sequencer indexes with (saved[kind][i][8], H[8], gamma[8], the FiLM
+// offsets) and every pointer it dereferences unconditionally is checked here, for every block of the plan.
+bool block_ok(const babe_unet_block& b, bool required) {
+    if (b.nd == 0 && !required) return true;
+    if (b.nd < 0 || b.nd > 8) return false;
+    if (required && b.nd < 1) return false;
+    if (b.N < G_GROUPS || b.N % G_GROUPS) return false;
+    for (int d = 0; d < b.nd; ++d) {
+        if (!b.gamma[d] || b.film_aff[d] < 0 || b.film_gate[d] < 0) return false;
+        const babe_packed_conv& h = b.H[d];
+        if (h.Cout != b.N || h.Cin != b.N || h.KH < 1 || h.KW < 1) return false;
+        if (!h.fwd && !h.w_raw && !h.fwd_wino45 && !h.fwd_wino4 && !h.fwd_wino) return false;      // no packed image at all
+    }
+    for (const babe_packed_conv* pc : {&b.proj_in, &b.res_conv, &b.proj_out})
+        if (pc->Cout != 0 && (pc->Cout < 0 || pc->Cin < 1 || (!pc->fwd && !pc->w_raw))) return false;
+    return true;
+}
 bool desc_ok(const babe_unet_plan_desc* d) {
     if (!d || d->nocts < 1 || d->nocts > 8 || d->bpo < 1) return false;
-    for (int i = 0; i < d->nocts; ++i)
-        if (d->Ns[i] % G_GROUPS || d->main_blk[i].nd > 8 || d->up_blk[i].nd > 8) return false;
-    return true;
+    for (int i = 0; i < d->nocts; ++i) {
+        if (d->Ns[i] < G_GROUPS || d->Ns[i] % G_GROUPS) return false;
+        if (!block_ok(d->init_blk[i], true) || !block_ok(d->main_blk[i], true) || !block_ok(d->up_blk[i], true) ||
+            !block_ok(d->up_out[i], true))
+            return false;
+    }
+    return block_ok(d->mid_blk, true) && block_ok(d->mid_out, true);
 }
 
 }  // namespace
 
 extern "C" void* babe_unet_plan_create(const babe_unet_plan_desc* desc) {
     if (!desc_ok(desc)) {
-        babe_set_error("unet_plan_create: bad descriptor (1..8 octaves, channels a multiple of 8, <= 8 dilation layers per block)");
+        babe_set_error("unet_plan_create: bad descriptor (1..8 octaves; every block: 1..8 dilation layers, channels a positive "
+                       "multiple of 8, gamma / FiLM offsets / packed weights present)");
         return nullptr;
     }
     auto* p = static_cast<babe_unet_plan_desc*>(malloc(sizeof(babe_unet_plan_desc)));

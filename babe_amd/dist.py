@@ -13,10 +13,15 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_results(x_local, fp_local, n_total=None):
+def gather_results(x_local, fp_local, n_total=None, force_collective=False):
     """x_local [b,L], fp_local [b,P] -> (x_all [n,L], fp_all [n,P]) on every rank, in global clip order.
-    Shards may differ by one clip; they are padded to the largest shard for the collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    Shards may differ by one clip; they are padded to the largest shard for the collective.
+    force_collective: run the collective even in a world of one rank (a one-GPU box can then execute the RCCL branch -
+    `init_process_group("nccl")` + `all_gather_into_tensor` - that an 8-GPU job takes: tests/test_gpu_dist.py, and bench.py
+    when torch.distributed.run launches it with one rank)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return x_local, fp_local
+    if dist.get_world_size() == 1 and not force_collective:
         return x_local, fp_local
     world = dist.get_world_size()
     b = torch.tensor([x_local.shape[0]], device=x_local.device, dtype=torch.int64)

@@ -196,19 +196,28 @@ class Unet_CQT_oct_with_attention(nn.Module):
 
     # ---------------------------------------------------------------- raw (no autograd) interface
     supports_lanes = True
-    # precision='bf16' and clip lanes.  Round 3 found that kernels containing packed-fp32 instructions returned wrong sums when they
-    # ran beside conv_bf16p on another stream; round 4 reduced it to one instruction form (tools/pk_opsel_min.hip):
-    # v_pk_{mul,add,fma}_f32 with op_sel:[0,1] reads the HIGH word of its second source as 0 while another kernel's waves execute
-    # bf16 MFMA on the same CU.  What may run beside the bf16 conv in the lane loop is therefore checked, not assumed:
-    #   * this library: built without packed fp32; tests/test_no_packed_fp32.py rejects any v_pk_*_f32 and any op_sel modifier;
-    #   * PyTorch kernels launched inside the lane loop: copies and fills only (profiles/r04_bench_bf16_kernel_stats.csv lists
-    #     every kernel of a run) - no fp32 arithmetic, hence no such instruction; the sampler draws its noise on the host
-    #     (noise_device='cpu', the reference's behaviour) BEFORE the lanes fork, and the RCCL gather runs after they join.
-    # With the cause known the round-3 precaution (one stream) is no longer the default; BABE_BF16_LANES=0 restores it (a host
-    # application that runs its OWN hipcc-default kernels on other streams beside this network should set it).
+    # precision='bf16' and clip lanes.  Kernels that contain the packed-fp32 form v_pk_{mul,add,fma}_f32 ... op_sel:[0,1] read the
+    # HIGH word of their second source as 0 while another kernel's waves execute bf16 MFMA on the same CU (reduced in round 4:
+    # tools/pk_opsel_min.hip, DESIGN.md "Co-residency finding").  THIS library contains no packed-fp32 instruction
+    # (babe_amd/build.py, tests/test_no_packed_fp32.py), but what ELSE runs beside conv_bf16p is outside its control: PyTorch's own
+    # kernels (device-side noise: bench.py's noise_device='cuda'), RCCL, a second process on the same GPU (two ranks on one
+    # device), a host application's hipcc-default kernels.  So a bf16 network keeps its batch items on ONE stream by default;
+    # BABE_BF16_LANES=1 opts in to two clip lanes (measured +13 %, profiles/r04_bench_bf16_two_lanes.json) for a host that knows
+    # what else it launches - and even then a live torch.distributed process group or device-side noise falls back to one
+    # stream (BlindSampler asks lanes_ok_for()).  The fp32 network has no bf16 MFMA anywhere and always runs two lanes.
     @property
     def concurrent_lanes_ok(self):
-        return self.precision != "bf16" or os.environ.get("BABE_BF16_LANES", "1") != "0"
+        return self.precision != "bf16" or os.environ.get("BABE_BF16_LANES", "0") == "1"
+
+    def lanes_ok_for(self, noise_device="cpu"):
+        """concurrent_lanes_ok narrowed by what the CALLER will launch beside the lanes: with precision='bf16' two lanes also
+        need host-side noise (torch.randn on the device is an ATen kernel inside the lane loop) and no live process group."""
+        if self.precision != "bf16":
+            return True
+        if not self.concurrent_lanes_ok:
+            return False
+        import torch.distributed as dist
+        return str(noise_device) == "cpu" and not (dist.is_available() and dist.is_initialized())
 
     def lane_engine(self, lane):
         """Engine state number `lane` (saved activations + scratch of its own over the shared packed weights): a caller that

@@ -5,6 +5,7 @@ apply_filter_istft :28-39, design_filter :82-119, apply_filter_and_norm_STFTmag_
 and BlindSampler.fit_params (/root/reference/testing/blind_bwe_sampler.py:533-595).
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -19,7 +20,7 @@ class FitCfg(C.Structure):
     _fields_ = [("mu_fc", C.c_float), ("mu_A", C.c_float), ("tol_fc", C.c_float), ("tol_A", C.c_float),
                 ("fcmin", C.c_float), ("fcmax", C.c_float), ("Amin", C.c_float), ("Amax", C.c_float),
                 ("max_iter", C.c_int), ("clamp_fc", C.c_int), ("clamp_A", C.c_int), ("only_negative_A", C.c_int),
-                ("weighting", C.c_int)]
+                ("weighting", C.c_int), ("kernel", C.c_int)]
 
 
 _registered = False
@@ -231,8 +232,13 @@ class STFTOps:
 
 
 def make_fit_cfg(mu=(1000.0, 10.0), tol=(5e-3, 5e-3), max_iter=100, fcmin=20.0, fcmax=22050.0, Amin=-50.0, Amax=30.0,
-                 clamp_fc=True, clamp_A=True, only_negative_A=True, weighting="sqrt"):
+                 clamp_fc=True, clamp_A=True, only_negative_A=True, weighting="sqrt", kernel=None):
+    """kernel: 0 = filter_fit_fast_kernel (default), 1 = the first, reference-order kernel; None takes the process default
+    (0 unless the A/B scripts under tools/ set BABE_FIT_FAST=0 - the choice is a field of babe_fit_cfg, not library state)."""
     c = FitCfg()
+    if kernel is None:
+        kernel = 1 if os.environ.get("BABE_FIT_FAST", "1") == "0" else 0
+    c.kernel = int(kernel)
     c.mu_fc, c.mu_A, c.tol_fc, c.tol_A = float(mu[0]), float(mu[1]), float(tol[0]), float(tol[1])
     c.fcmin, c.fcmax, c.Amin, c.Amax = float(fcmin), float(fcmax), float(Amin), float(Amax)
     c.max_iter, c.clamp_fc, c.clamp_A, c.only_negative_A = int(max_iter), int(clamp_fc), int(clamp_A), int(only_negative_A)

@@ -377,9 +377,11 @@ class BlindSampler:
         B, L = x.shape
         T = self.nb_steps
         dev = x.device
-        # (a network that must not run two chains at once - precision='bf16', see concurrent_lanes_ok - gets ONE lane
+        # (a network that must not run two chains at once - precision='bf16' without the opt-in, see lanes_ok_for - gets ONE lane
         # with the whole batch: same launches as the plain loop, on one stream, but graph-captured)
-        nl = min(self.LANES, B) if getattr(self.model, "concurrent_lanes_ok", True) else 1
+        ok_for = getattr(self.model, "lanes_ok_for", None)
+        lanes_ok = ok_for(self.noise_device) if ok_for is not None else getattr(self.model, "concurrent_lanes_ok", True)
+        nl = min(self.LANES, B) if lanes_ok else 1
         per = -(-B // nl)
         main = torch.cuda.current_stream(dev)
         if getattr(self, "_lane_streams", None) is None or len(self._lane_streams) < nl:

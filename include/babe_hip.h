@@ -116,6 +116,10 @@ int babe_prof_enable(int on);          /* on < 0: query, returns 1 / 0 */
 int babe_prof_conv_slot(int slot);      /* >= 0: tally conv launches in that slot (the CQT's dense DFT stages); -1: off */
 int babe_prof_read(double* ms, double* bytes, double* flops, double* exec_flops, long* launches);
 int babe_prof_dispatch_counts(long* counts, int reset);
+/* per-launch timeline of the records pending since the last babe_prof_read (call before it): event times in ms relative to the
+ * first record, slot, lane (stream index in order of first appearance), tallied flops; returns the count written (<= cap) */
+long babe_prof_timeline(double* t0_ms, double* t1_ms, int* slot, int* lane, double* flops, long cap);
+long babe_prof_pending(void);
 
 /* ---- BiasFreeGroupNorm + FiLM + GELU: cqtdiff+.py:147-163, :472-482 ------------------------ */
 /* partial sums (double) of x and x^2 per (b,group,split): part[(b*G+g)*S+s] = {sum, sumsq} */
@@ -295,6 +299,9 @@ int babe_design_filter(const float* params, float* H, int P, int K, int nbins, f
 typedef struct {
     float mu_fc, mu_A, tol_fc, tol_A, fcmin, fcmax, Amin, Amax;
     int max_iter, clamp_fc, clamp_A, only_negative_A, weighting; /* 0 None, 1 sqrt, 2 linear, 3 log */
+    int kernel;  /* 0: filter_fit_fast_kernel (register-resident, v_exp/v_log segments; default), 1: filter_fit_kernel, the first
+                  * kernel, which keeps the reference's operation order inside an iteration; both are pinned against the same
+                  * goldens, and against each other over full runs (tests/test_gpu_stft.py) */
 } babe_fit_cfg;
 /* BlindSampler.fit_params (:533-595): projected gradient descent on (fc, A) from the statistics.
  * params [P][2][K] updated in place; n_iter[P] receives the iteration count. K <= 8. */

@@ -40,3 +40,56 @@ def test_unet_plan_structs_have_the_headers_layout(tmp_path):
     got = [ctypes.sizeof(uc.CPackedConv), ctypes.sizeof(uc.CBlock), ctypes.sizeof(uc.CPlanDesc), uc.CPackedConv.w_raw.offset,
            uc.CBlock.gamma.offset, uc.CBlock.film_gate.offset, uc.CPlanDesc.pyr_conv.offset]
     assert got == want, (got, want)
+
+
+def test_unet_plan_create_validates_every_block():
+    """babe_unet_plan_create takes descriptors from any C-ABI host: a dilation-layer count outside 0..8 (it indexes saved[..][8],
+    H[8], gamma[8]), a channel count that is not a positive multiple of the 8 GroupNorm groups, or a missing gamma / packed image
+    in ANY block - init, main, up, out, middle - is refused with a message instead of overrunning.  Host-side
+    validation only: no GPU call is made."""
+    from babe_amd._lib import lib
+    from babe_amd.networks import unet_c as uc
+    uc._register()
+    L = lib()
+    FAKE = 0x1000                                         # never dereferenced by plan_create (pointers stay the caller's)
+
+    def good():
+        d = uc.CPlanDesc()
+        d.nocts, d.bpo = 2, 64
+        for i in range(2):
+            d.Ns[i] = 16
+        def blk(b, nd):
+            b.N, b.nd, b.k53 = 16, nd, 1
+            for k in range(nd):
+                b.H[k].Cout = b.H[k].Cin = 16
+                b.H[k].KH, b.H[k].KW = 5, 3
+                b.H[k].fwd = FAKE
+                b.gamma[k] = FAKE
+        for i in range(2):
+            for arr in (d.init_blk, d.main_blk, d.up_out, d.up_blk):
+                blk(arr[i], 2)
+        blk(d.mid_blk, 3)
+        blk(d.mid_out, 1)
+        return d
+
+    def create(d):
+        p = L.babe_unet_plan_create(ctypes.byref(d))
+        if p:
+            L.babe_unet_plan_destroy(p)
+        return bool(p), L.babe_last_error().decode()
+
+    assert create(good())[0]
+    for name, mutate in {
+        "init_blk nd 9": lambda d: setattr(d.init_blk[1], "nd", 9),
+        "up_out nd -1": lambda d: setattr(d.up_out[0], "nd", -1),
+        "mid_blk nd 12": lambda d: setattr(d.mid_blk, "nd", 12),
+        "mid_out nd 0": lambda d: setattr(d.mid_out, "nd", 0),
+        "main_blk N 12": lambda d: setattr(d.main_blk[0], "N", 12),
+        "up_blk gamma NULL": lambda d: d.up_blk[1].gamma.__setitem__(1, None),
+        "main_blk H without image": lambda d: setattr(d.main_blk[1].H[0], "fwd", None),
+        "Ns not a multiple of 8": lambda d: d.Ns.__setitem__(1, 20),
+    }.items():
+        d = good()
+        mutate(d)
+        ok, msg = create(d)
+        assert not ok and "bad descriptor" in msg, (name, ok, msg)

@@ -105,3 +105,25 @@ def test_restore_clips_sharded_world2_equals_world1():
     assert x1.shape == (3, 1700) and f1.shape == (3, 8)
     for _, x2, f2 in res:
         assert (x2 == x1).all() and (f2 == f1).all()
+
+
+def _worker_w1(port, q):
+    from babe_amd.dist import gather_results
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    x, fp = torch.arange(48.0).reshape(3, 16), torch.arange(30.0).reshape(3, 10)
+    x0, _ = gather_results(x, fp)                                   # world of one: inputs returned untouched
+    x1, f1 = gather_results(x, fp, force_collective=True)           # ... unless the collective is forced (the RCCL smoke's switch)
+    q.put((x0 is x, x1 is x, bool(torch.equal(x1, x) and torch.equal(f1, fp))))
+    dist.destroy_process_group()
+
+
+def test_gather_world1_force_collective():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_w1, args=(_free_port(), q))
+    p.start()
+    same0, same1, equal = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0 and same0 and not same1 and equal

@@ -59,3 +59,63 @@ def test_bench_two_ranks_shared_gpu_prints_its_line():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["output_finite"] is True and d["value"] > 0
+
+
+def _env_nccl():
+    e = dict(os.environ)
+    e.pop("BABE_DIST_BACKEND", None)                     # default backend = nccl (RCCL on ROCm)
+    e["MASTER_ADDR"] = "127.0.0.1"
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return e
+
+
+_NCCL_W1 = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from babe_amd.dist import gather_results
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+g = torch.Generator().manual_seed(3)
+x = torch.randn(3, 4099, generator=g).to(dev)
+fp = torch.randn(3, 20, generator=g).to(dev)
+# without the flag a world of one returns its inputs untouched; with it the padded buffer goes through all_gather_into_tensor
+x0, fp0 = gather_results(x, fp)
+assert x0 is x and fp0 is fp
+x1, fp1 = gather_results(x, fp, force_collective=True)
+torch.cuda.synchronize()
+assert x1 is not x and x1.shape == x.shape and fp1.shape == fp.shape
+assert torch.equal(x1, x) and torch.equal(fp1, fp)
+# an empty shard (a rank without clips) still takes part
+xe, fpe = gather_results(x[:0], fp[:0], force_collective=True)
+assert xe.shape == (0, 4099) and fpe.shape == (0, 20)
+dist.barrier()
+dist.destroy_process_group()
+print("NCCL_W1_OK")
+"""
+
+
+def test_rccl_branch_of_gather_results_world_size_one():
+    """The `nccl` branch of gather_results (init_process_group("nccl", device_id=...), all_gather of the shard sizes,
+    all_gather_into_tensor on the padded buffer) executed on the one GPU a test box has: a world of ONE rank with the
+    early return bypassed.  (Two RCCL ranks on one device are refused by RCCL; the 8-GPU job is the driver's.)"""
+    e = _env_nccl()
+    e["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, "-c", _NCCL_W1, ROOT], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NCCL_W1_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_bench_one_rank_under_torchrun_takes_the_rccl_path():
+    """`torchrun --nproc-per-node 1 bench.py --gpus 1`: the launch path of the driver's N > 1 runs with one rank - process
+    group on RCCL, barrier, end-of-step all_gather_into_tensor, max-over-ranks all_reduce - and the line says so."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                        "--T", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--profile-steps", "0"],
+                       env=_env_nccl(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["output_finite"] is True and d["value"] > 0
+    assert "RCCL all_gather" in d["config"]["parallelism"], d["config"]["parallelism"]

@@ -35,6 +35,10 @@ class ResidualNet:
     def concurrent_lanes_ok(self):
         return getattr(self.inner, "concurrent_lanes_ok", True)
 
+    def lanes_ok_for(self, noise_device="cpu"):
+        f = getattr(self.inner, "lanes_ok_for", None)
+        return f(noise_device) if f is not None else self.concurrent_lanes_ok
+
     def fwd_nograd(self, x, cn, lane=None):
         self.k = float(torch.exp(4 * cn[0, 0])) / self.sd          # (one sigma per call; same for every lane of a step)
         kw = {} if lane is None else {"lane": lane}

@@ -73,8 +73,50 @@ def test_guidance_forward_and_vjp():
     assert rel(gx, gref) < 2e-5
 
 
+def _fit_case(ci):
+    from babe_amd.stft import STFTOps
+    g = load("fit_params.npz")
+    seed, B, n = int(g[f"fit{ci}_seed"]), int(g[f"fit{ci}_B"]), int(g[f"fit{ci}_n"])
+    fc_true, A_true = [float(v) for v in g[f"fit{ci}_true"]]
+    gen = torch.Generator().manual_seed(seed)
+    xd = torch.randn(B, n, generator=gen) * 0.1
+    f = U.bin_freqs(4096, 44100)
+    y = U.apply_filter(xd, U.design_filter(torch.tensor([fc_true]), torch.tensor([A_true]), f), 4096) \
+        + 1e-3 * torch.randn(B, n, generator=gen)
+    st = STFTOps(4096, n, 44100, "cuda")
+    stats = st.mag_stats(st.stft(xd.cuda()), st.stft(y.cuda()), shared=True)
+    p0 = torch.tensor([[[280.0, 285.0, 290.0, 295.0, 300.0], [-15.0, -17.0, -20.0, -25.0, -30.0]]])
+    return st, stats, p0
+
+
 @pytest.mark.parametrize("ci", [0, 1, 2])
-def test_filter_fit_vs_golden(ci):
+def test_fast_fit_kernel_vs_reference_order_kernel_full_runs(ci):
+    """babe_fit_cfg.kernel: 0 = filter_fit_fast_kernel (default: v_exp / v_log segment evaluation, re-associated sums), 1 =
+    filter_fit_kernel (the reference's operation order inside an iteration).  Pinned against each other on the golden
+    statistics over FULL runs, not only the first iterations:
+      * mu = [100, 1] (the contractive setting of the B = 2 goldens): 100 iterations allowed, same iteration count,
+        parameters to 1e-4 relative / 1e-3 dB per octave;
+      * the default mu = [1000, 10], under which the reference's own iteration oscillates and amplifies 1e-7 input differences
+        (DESIGN.md 4): the bar of the golden's final-parameter check (fc 1 %, A 0.5 dB per octave)."""
+    from babe_amd.stft import make_fit_cfg
+    st, stats, p0 = _fit_case(ci)
+    for mu, rt, at in (((100.0, 1.0), 1e-4, 1e-3), ((1000.0, 10.0), 1e-2, 0.5)):
+        res = []
+        for kern in (0, 1):
+            p = p0.clone().cuda()
+            nit = st.filter_fit(stats, p, make_fit_cfg(mu=mu, fcmax=22050, kernel=kern))
+            res.append((p[0].cpu(), [int(v) for v in nit.reshape(-1).tolist()]))
+        (pf, nf), (pr, nr) = res
+        print(f"fit case {ci} mu={mu}: iterations fast {nf} / reference-order {nr}; max |dfc| "
+              f"{float((pf[0] - pr[0]).abs().max()):.3e} Hz, max |dA| {float((pf[1] - pr[1]).abs().max()):.3e} dB/oct")
+        assert torch.allclose(pf[0], pr[0], rtol=rt) and torch.allclose(pf[1], pr[1], atol=at), (mu, pf, pr)
+        if mu[0] == 100.0:
+            assert nf == nr, (nf, nr)
+
+
+@pytest.mark.parametrize("kern", [0, 1])
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_filter_fit_vs_golden(ci, kern):
     from babe_amd.stft import STFTOps, make_fit_cfg
     g = load("fit_params.npz")
     seed, B, n = int(g[f"fit{ci}_seed"]), int(g[f"fit{ci}_B"]), int(g[f"fit{ci}_n"])
@@ -89,9 +131,9 @@ def test_filter_fit_vs_golden(ci):
     p0 = torch.tensor([[[280.0, 285.0, 290.0, 295.0, 300.0], [-15.0, -17.0, -20.0, -25.0, -30.0]]])
     for mi in (1, 2, 5):
         p = p0.clone().cuda()
-        st.filter_fit(stats, p, make_fit_cfg(max_iter=mi, fcmax=22050))
+        st.filter_fit(stats, p, make_fit_cfg(max_iter=mi, fcmax=22050, kernel=kern))
         assert torch.allclose(p[0].cpu(), g[f"fit{ci}_it{mi}"], rtol=5e-5, atol=5e-4), (mi, p, g[f"fit{ci}_it{mi}"])
     p = p0.clone().cuda()
-    nit = st.filter_fit(stats, p, make_fit_cfg(fcmax=22050))
+    nit = st.filter_fit(stats, p, make_fit_cfg(fcmax=22050, kernel=kern))
     ref = g[f"fit{ci}_final"]
     assert torch.allclose(p[0, 0].cpu(), ref[0], rtol=1e-2) and torch.allclose(p[0, 1].cpu(), ref[1], atol=0.5), (p, ref, nit)

@@ -66,3 +66,38 @@ def test_counted_vmcnt_kernel_issues_the_vector_memory_ops_its_counts_assume(tmp
             assert len(dma) == 21 and len(rows) >= 15 and len(waits) >= 4, (head, len(dma), len(rows), len(waits))
             seen += 1
     assert seen == 4, f"expected the four instantiations of conv_wino45x_kernel, found {seen}"
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump not available")
+def test_conv11p_ring_issues_the_lds_dma_its_counted_wait_assumes(tmp_path):
+    """conv11p_kernel<NT, NPW, ISC> (csrc/conv11p.hip) moves both operands by inline-asm LDS-DMA (`buffer_load_dwordx4 ... lds`)
+    and synchronises before the last K-step of a slab with `s_waitcnt vmcnt(XJ + WJ)`: each wave waits for its part of slab
+    j + 1 while the XJ + WJ DMA instructions of slab j + 2 stay in flight.  The count is valid only while exactly those
+    instructions are the youngest vector-memory operations: XJ = 2 NPW activation chunks + WJ = ceil(NT / 2) weight chunks per
+    slab, issued three times in the kernel text (two prologue slabs + the loop body).  Checked on the disassembly."""
+    import re
+    from babe_amd.build import build
+    so = build(verbose=False)
+    local = tmp_path / "libbabe_hip.so"
+    shutil.copy(so, local)
+    subprocess.run([OBJDUMP, "--offloading", str(local)], check=True, capture_output=True)
+    bundles = [p for p in glob.glob(str(local) + ".*") if "amdgcn" in p]
+    seen = set()
+    for b in bundles:
+        asm = subprocess.run([OBJDUMP, "-d", b], check=True, capture_output=True, text=True).stdout
+        for chunk in asm.split("\n\n"):
+            head = chunk.lstrip().splitlines()[0] if chunk.strip() else ""
+            m = re.search(r"conv11p_kernelILi(\d)ELi(\d)ELb([01])EE", head)
+            if not m:
+                continue
+            nt, npw = int(m.group(1)), int(m.group(2))
+            xj, wj = 2 * npw, (nt + 1) // 2
+            ins = [l.split("//")[0].strip() for l in chunk.splitlines()[1:]]
+            dma = [l for l in ins if l.startswith("buffer_load_dwordx4") and " lds" in l]
+            waits = [l for l in ins if l.startswith(f"s_waitcnt vmcnt({xj + wj})")]
+            m0 = [l for l in ins if l.startswith("s_mov_b32 m0")]
+            assert len(dma) == 3 * (xj + wj), (head, len(dma), xj, wj)
+            assert len(waits) >= 1, (head, "counted wait missing")
+            assert len(m0) >= len(dma), (head, "every asm DMA sets m0 itself")
+            seen.add((nt, npw, m.group(3)))
+    assert len(seen) == 16, f"expected the 16 instantiations of conv11p_kernel, found {sorted(seen)}"
