@@ -116,22 +116,6 @@ def prof_slot_names():
 
 _prof_on = False
 
-# Generation of the PERSISTENT device allocations a captured HIP graph may hold raw pointers to: engine scratch, packed
-# weights, lazily built STFT / CQT tables.  Whoever (re)allocates one of them bumps it; the sampler's graph cache records the
-# generation it captured under and drops every graph when it has moved (blind_bwe_sampler.BlindSampler._sample_lanes): a
-# replay must never write through a pointer whose tensor has been freed.
-_alloc_gen = 0
-
-
-def bump_alloc_generation():
-    global _alloc_gen
-    _alloc_gen += 1
-
-
-def alloc_generation():
-    return _alloc_gen
-
-
 def prof_enable(on):
     """Measurement hook (include/babe_hip.h): HIP-event timing of every launch, tallied per kernel slot."""
     global _prof_on
@@ -140,8 +124,8 @@ def prof_enable(on):
 
 
 def prof_enabled():
-    """True while the measurement hook is on (its HIP events cannot be part of a captured graph).  Asks the LIBRARY: a direct
-    babe_prof_enable call from another binding must keep graph capture off too (babe_prof_enable(-1) = query)."""
+    """True while the measurement hook is on.  Asks the LIBRARY (babe_prof_enable(-1) = query): another binding may have
+    switched it on."""
     return bool(_prof_on or (lib().babe_prof_enable(-1) == 1))
 
 

@@ -263,8 +263,6 @@ class CQT_nsgt:
 
     def __init__(self, numocts, binsoct, mode="oct", window=("kaiser", 1), fs=44100, audio_len=44100,
                  device="cuda", dtype=torch.float32):
-        from ._lib import bump_alloc_generation
-        bump_alloc_generation()              # new tables (captured HIP graphs may point at a plan this one replaces)
         if mode != "oct":
             raise NotImplementedError("only mode='oct' is implemented")
         if not (isinstance(window, (tuple, list)) and window[0] == "kaiser"):

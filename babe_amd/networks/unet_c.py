@@ -7,7 +7,7 @@ import ctypes as C
 
 import torch
 
-from .._lib import bump_alloc_generation, check, lib, ptr, stream
+from .._lib import check, lib, ptr, stream
 
 _I, _P = C.c_int, C.c_void_p
 
@@ -136,7 +136,6 @@ class CUnet:
                 raise RuntimeError("babe_unet_workspace_bytes: " + L.babe_last_error().decode())
             self.ws = torch.empty(nbytes, device=C_list[0].device, dtype=torch.uint8)
             self.key = key
-            bump_alloc_generation()              # captured graphs hold the old workspace's address
         outs = [torch.empty_like(c) for c in C_list]
         cin = (_P * n)(*[ptr(c) for c in C_list])
         cout = (_P * n)(*[ptr(o) for o in outs])

@@ -17,7 +17,6 @@ import os
 import torch
 
 from .. import ops
-from .._lib import bump_alloc_generation
 
 RS2 = 1.0 / math.sqrt(2.0)
 # the library-side sequencer (csrc/unet_engine.hip): one C call per direction.  BABE_UNET_C=1 enables it (fp32 networks).
@@ -121,7 +120,6 @@ class UnetEngine:
         if t is None or t.numel() < numel:
             t = torch.empty(numel, device=self.dev, dtype=torch.float32)
             self._scratch[name] = t
-            bump_alloc_generation()          # captured HIP graphs hold the old tensor's address
         return t[:numel]
 
     def scratch_i16(self, name, numel):
@@ -129,7 +127,6 @@ class UnetEngine:
         if t is None or t.numel() < numel:
             t = torch.empty(numel, device=self.dev, dtype=torch.int16)
             self._scratch[name] = t
-            bump_alloc_generation()
         return t[:numel]
 
     def embed(self, cnoise):

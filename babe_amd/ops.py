@@ -39,8 +39,6 @@ class PackedConv:
         self.precision = precision
         self.nt = nt
         self.splits = PRECISIONS[precision]
-        from ._lib import bump_alloc_generation
-        bump_alloc_generation()              # (re-)packed weights: graphs captured over an older pack must not be replayed
         # Shapes that gain nothing from bf16 MFMA run on the fp32 kernels whatever the requested precision (exact AND at
         # least as fast): convs with <= 4 channels on one side (few-channel kernels), (1,1) kernels with fewer than 32
         # channels on one side (HBM-bound: all-DMA kernel), and every (1,1) kernel of the bf16x3 mode.  Wide (1,1) kernels are
@@ -175,8 +173,6 @@ def _gn_ticket(dev, n):
     if t is None or t.numel() < n:
         t = torch.zeros(max(n, 1024), device=dev, dtype=torch.int32)
         _GN_TICKETS[key] = t
-        from ._lib import bump_alloc_generation
-        bump_alloc_generation()
     return t
 
 

@@ -4,12 +4,12 @@
                                [--denoise [--denoiser-ckpt denoiser.pt]]
 
 Follows the reference's file-level flow (testing/blind_bwe_tester.py:321-577 formal_test_bwe, blind mode):
-read -> (resample is NOT done here: the file must already be at exp.sample_rate) -> normalise to sigma_norm std
--> segments + blind restoration + cross-fade (babe_amd/testing/long_file.py) -> write wav + filter pickle.
+read -> resample to exp.sample_rate (:410, babe_amd/resample.py = torchaudio.functional.resample as published; a 48 kHz file is
+accepted) -> normalise to sigma_norm std -> segments + blind restoration + cross-fade (babe_amd/testing/long_file.py) -> write wav
+(at exp.sample_rate, like the reference) + filter pickle.
 Without --ckpt the network has random weights (useful only to exercise the path).
---denoise runs the denoiser pre-pass first (testing/denoise_and_bwe_tester.py:279-285: apply_denoiser on the whole file,
-then the BWE on its output); it needs the file at the denoiser's rate (sample_rate_denoiser == exp.sample_rate: the
-torchaudio resampling of the reference is not part of this build).
+--denoise runs the denoiser pre-pass first (testing/denoise_and_bwe_tester.py:279-289: file rate -> --denoiser-rate (22050) ->
+apply_denoiser on the whole file -> exp.sample_rate, then the BWE on its output).
 """
 import argparse
 import os
@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--sigma-norm", type=float, default=0.1)
     ap.add_argument("--denoise", action="store_true", help="denoiser pre-pass before the bandwidth extension")
     ap.add_argument("--denoiser-ckpt", help="state_dict of networks.denoiser.MultiStage_denoise")
+    ap.add_argument("--denoiser-rate", type=int, default=22050, help="tester.denoiser.sample_rate_denoiser")
     a = ap.parse_args()
     from .config import default_args
     from .diff_params.edm import EDM
@@ -41,25 +42,32 @@ def main():
     net = Unet_CQT_oct_with_attention(args, "cuda", precision=a.precision)
     if a.ckpt:
         load_checkpoint(net, a.ckpt)
+    from .resample import resample
     y, sr = read_audio_file(a.wav)
-    if sr != a.sample_rate:
-        raise SystemExit(f"{a.wav} is sampled at {sr} Hz; resample it to {a.sample_rate} Hz first")
     y = y.cuda()
     if a.denoise:
         from .networks.denoiser import MultiStage_denoise
         from .testing.denoise import DenoiserPrepass
-        dargs = dict(sample_rate_denoiser=a.sample_rate, segment_size=5, stft_win_size=1024, stft_hop_size=256, depth=6,
+        dargs = dict(sample_rate_denoiser=a.denoiser_rate, segment_size=5, stft_win_size=1024, stft_hop_size=256, depth=6,
                      num_tfc=3, num_stages=2, use_SAM=True, use_fencoding=True, f_dim=513)   # blind_bwe_denoise*.yaml `denoiser:`
         dnet = MultiStage_denoise(dargs)
         if a.denoiser_ckpt:
             dnet.load_state_dict(torch.load(a.denoiser_ckpt, map_location="cpu"))
+        # denoise_and_bwe_tester.py:279-289 (both conversions hang on fs != sample_rate_denoiser there; a file already at the
+        # denoiser's rate still has to reach the model's rate here, or the segment lengths below would not be the model's)
+        if sr != a.denoiser_rate:
+            y = resample(y, sr, a.denoiser_rate)
         y = DenoiserPrepass(dnet.to("cuda"), dargs, "cuda").apply_denoiser(y.unsqueeze(0))[0]
+        if a.denoiser_rate != a.sample_rate:
+            y = resample(y, a.denoiser_rate, a.sample_rate)
+    else:
+        y = resample(y, sr, a.sample_rate)                   # blind_bwe_tester.py:410 (the input itself at equal rates)
     std = float(y.std())
     y = y * (a.sigma_norm / std)
     sampler = BlindSampler(net, EDM(args), args, batch_semantics="per_clip")
     out, filt = restore_file(sampler, y, batch_size=a.batch)
     name = os.path.splitext(os.path.basename(a.wav))[0]
-    p = write_audio_file(out * (std / a.sigma_norm), sr, name, a.out_dir)
+    p = write_audio_file(out * (std / a.sigma_norm), a.sample_rate, name, a.out_dir)
     write_filter_data(filt, a.out_dir, name)
     print(p)
 

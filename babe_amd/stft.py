@@ -116,8 +116,6 @@ class STFTOps:
 
     def __init__(self, nfft, L, fs, device):
         _register()
-        from ._lib import bump_alloc_generation
-        bump_alloc_generation()              # new tables: captured HIP graphs may point at the plan this one replaces
         self.nfft, self.L, self.fs, self.dev = int(nfft), int(L), float(fs), torch.device(device)
         self.hop = self.nfft // 2
         self.frames = 1 + self.L // self.hop

@@ -76,7 +76,7 @@ class BlindSampler:
         # observation-noise regularisation (get_rec_grads :80-86, fit_params :542-552; conf/tester/blind_bwe_2.yaml sets
         # SNR_observations: 50): the observations receive fresh noise IN PLACE before every fit and before every guidance
         # evaluation, and the fit may see a noisy copy of the denoised estimate.  The draws interleave with the step noise, so
-        # these modes run the single-stream loop (no lanes, no graphs) and draw in the reference's order.
+        # these modes run the single-stream loop (no lanes) and draw in the reference's order.
         snr_db = ps.get("SNR_observations", "None")
         self.obs_snr = None if snr_db == "None" else 10.0 ** (float(snr_db) / 10.0)
         self.sigma_den = float(bb.get("sigma_den_estimate", 0) or 0)
@@ -353,32 +353,17 @@ class BlindSampler:
             d2, _, ln["fp"] = self.evaluate(x_prime, float(t[i + 1]), ln["y"], ln["specY"], ln["fp"], blind, ln["k"])
             ln["x"] = lincomb(torch.empty_like(x_prime), 1.0, ln["x_hat"], 0.5 * h, ln["d"], 0.5 * h, d2)
 
-    # HIP graphs (opt-in: BABE_SAMPLER_GRAPHS=1): the launches of one Heun step of one lane (two score evaluations: ~2200
-    # kernels) are captured once per (shape, schedule, configuration) and replayed.  Every per-step scalar (sigma,
-    # preconditioning, step size) is a launch argument baked into the graph of ITS step, the filter fit's early exit is
-    # device-side, noise / observations / initial state live in static buffers that are refilled before a replay.  First
-    # call with a configuration: eager (it also creates every lazily-built table); second: capture + replay; later:
-    # replay.  Results are bit-identical to the eager loop (same kernels, same order:
-    # tests/test_gpu_sampler.py::test_graph_replay_equals_eager).  The measurement hook (HIP events around every launch)
-    # forces the eager loop.
-    # OFF by default because it buys nothing here - measured on the benchmark (round 3, same box, 4 timed steps): f32 two
-    # lanes 1.665 (graphs) vs 1.671 (eager) audio-sec/s, bf16 one lane 3.209 vs 3.234.  The eager loop has no host sync
-    # (the reference syncs every step, :587, :729) and enqueues an evaluation in 26 ms of Python (f32; bf16 10 ms) while
-    # the GPU needs 59 ms (25 ms) for it (tools/host_enqueue_time.py): the queues never run dry, so there is no launch gap
-    # for a graph to close, and a replayed graph dispatches its ~2200 nodes no faster than the stream does.
-    GRAPHS = os.environ.get("BABE_SAMPLER_GRAPHS", "0") == "1"
-
-    def _graph_key(self, x, blind, snoise, t, gamma, filter_params, nl):
-        return (tuple(x.shape), str(x.device), bool(blind), float(snoise), tuple(float(v) for v in t),
-                tuple(float(v) for v in gamma), tuple(filter_params.shape), nl, self.order, float(self.xi),
-                self.batch_semantics, id(self.model), id(self._stft))
-
+    # (Rounds 2-4 carried an opt-in HIP-graph replay of the lanes' Heun steps, BABE_SAMPLER_GRAPHS=1.  Measured again on the
+    # driver's command in round 5, same box: 2.129 (graphs) vs 2.140 / 2.140 (eager) audio-sec/s - the eager loop has no host
+    # sync and enqueues an evaluation in 17 ms of Python against 34 ms of GPU time per evaluation and lane, so there is no launch
+    # gap for a graph to close.  Removed, with its pointer-lifetime bookkeeping: one way to sequence the sampler from Python -
+    # this loop - and one for a non-Python host, the library-side UNet sequencer csrc/unet_engine.hip.)
     def _sample_lanes(self, x, y, specY, filter_params, blind, snoise, t, gamma):
         B, L = x.shape
         T = self.nb_steps
         dev = x.device
         # (a network that must not run two chains at once - precision='bf16' without the opt-in, see lanes_ok_for - gets ONE lane
-        # with the whole batch: same launches as the plain loop, on one stream, but graph-captured)
+        # with the whole batch: same launches as the plain loop, on one stream)
         ok_for = getattr(self.model, "lanes_ok_for", None)
         lanes_ok = ok_for(self.noise_device) if ok_for is not None else getattr(self.model, "concurrent_lanes_ok", True)
         nl = min(self.LANES, B) if lanes_ok else 1
@@ -387,32 +372,6 @@ class BlindSampler:
         if getattr(self, "_lane_streams", None) is None or len(self._lane_streams) < nl:
             self._lane_streams = [torch.cuda.Stream(device=dev) for _ in range(nl)]
         noises = [self._randn((B, L), dev).contiguous() for _ in range(T)]          # reference order: one draw per step
-        from .._lib import prof_enabled, alloc_generation
-        if not hasattr(self, "_graphs"):
-            self._graphs = {}
-        # graphs bake raw device pointers (engine scratch, packed weights, STFT / CQT tables) that they do not keep alive:
-        # whenever one of those has been (re)allocated since a capture - a later eager call with a larger batch or length, a
-        # second configuration's first call, re-packed weights - every captured graph is dropped (never replayed)
-        if getattr(self, "_graphs_gen", None) != alloc_generation():
-            self._graphs = {k_: {} for k_, v_ in self._graphs.items() if not v_.get("failed")}
-            self._graphs_gen = alloc_generation()
-        key = self._graph_key(x, blind, snoise, t, gamma, filter_params, nl)
-        gs = self._graphs.get(key) if (self.GRAPHS and not prof_enabled()) else None
-        if gs is not None and gs.get("failed"):
-            gs = None
-        if gs is not None:
-            if "graphs" not in gs:
-                try:
-                    self._capture_lanes(gs, x, y, specY, filter_params, blind, snoise, t, gamma, noises, nl, per)
-                except Exception as e:                      # loud, then the eager loop: a capture problem must not cost results
-                    import warnings
-                    warnings.warn(f"BlindSampler: HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly")
-                    self._graphs[key] = dict(failed=True)
-                    gs = None
-            if gs is not None:
-                return self._replay_lanes(gs, x, y, specY, filter_params, noises, main)
-        elif self.GRAPHS and not prof_enabled() and key not in self._graphs:
-            self._graphs[key] = {}                          # seen once: the next call with this configuration captures
         lanes = []
         for k in range(nl):
             b0, b1 = k * per, min(B, (k + 1) * per)
@@ -437,58 +396,6 @@ class BlindSampler:
         for n_ in noises:
             for ln in lanes:
                 n_.record_stream(ln["st"])
-        return torch.cat([ln["x"] for ln in lanes], 0), torch.cat([ln["fp"] for ln in lanes], 0)
-
-    def _capture_lanes(self, gs, x, y, specY, filter_params, blind, snoise, t, gamma, noises, nl, per):
-        """Capture one graph per (lane, Heun step) over static input buffers; the lanes' graphs share one memory pool per
-        lane (replayed in capture order, never concurrently within a lane)."""
-        B, L = x.shape
-        T = self.nb_steps
-        torch.cuda.synchronize(x.device)
-        st = dict(x=torch.empty_like(x), y=torch.empty_like(y), specY=torch.empty_like(specY),
-                  fp=torch.empty_like(filter_params), noise=[torch.empty_like(n_) for n_ in noises])
-        lanes, graphs = [], []
-        for k in range(nl):
-            b0, b1 = k * per, min(B, (k + 1) * per)
-            if b0 >= b1:
-                continue
-            ln = dict(k=k, st=self._lane_streams[k], sl=slice(b0, b1), x=st["x"][b0:b1], y=st["y"][b0:b1],
-                      specY=st["specY"][b0:b1], fp=st["fp"][b0:b1])
-            pool = torch.cuda.graph_pool_handle()
-            gl = []
-            for i in range(T):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=ln["st"]):
-                    self._lane_step(ln, i, t, gamma, st["noise"][i], blind, snoise, 0)
-                    self._lane_step(ln, i, t, gamma, st["noise"][i], blind, snoise, 1)
-                gl.append(g)
-            lanes.append(ln)
-            graphs.append(gl)
-        gs.update(static=st, lanes=lanes, graphs=graphs)
-        from .._lib import alloc_generation
-        self._graphs_gen = alloc_generation()               # (allocations made DURING the capture belong to the graphs' pools)
-
-    def _replay_lanes(self, gs, x, y, specY, filter_params, noises, main):
-        st, lanes, graphs = gs["static"], gs["lanes"], gs["graphs"]
-        st["x"].copy_(x)
-        st["y"].copy_(y)
-        st["specY"].copy_(specY)
-        st["fp"].copy_(filter_params)
-        for dst, src in zip(st["noise"], noises):
-            dst.copy_(src)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        for ln in lanes:
-            ln["st"].wait_event(ready)
-        for i in range(self.nb_steps):
-            for ln, gl in zip(lanes, graphs):
-                with torch.cuda.stream(ln["st"]):
-                    gl[i].replay()
-        for ln in lanes:
-            done = torch.cuda.Event()
-            done.record(ln["st"])
-            main.wait_event(done)
-        # (copies on `main`, after the lanes: the static outputs are overwritten by the next replay)
         return torch.cat([ln["x"] for ln in lanes], 0), torch.cat([ln["fp"] for ln in lanes], 0)
 
     def _init_params(self, B, device):

@@ -123,7 +123,7 @@ def restore_file_AR(sampler, y, filt, filt_type="fc_A", overlap_s=0.25, discard_
 
 
 def restore_recording_complete(sampler, degraded, *, n_segments_blindstep=1, ix_start=0, std=0.1, overlap_s=0.25,
-                               typefilter="fc_A", denoiser=None, rng=None):
+                               typefilter="fc_A", denoiser=None, rng=None, fs=None, sample_rate_denoiser=None):
     """Whole-recording flow of BlindTester.test_real_blind_bwe_complete (/root/reference/testing/blind_bwe_tester.py:
     710-867; with the denoiser pre-pass: testing/denoise_and_bwe_tester.py:248-411, config #5):
 
@@ -136,15 +136,28 @@ def restore_recording_complete(sampler, degraded, *, n_segments_blindstep=1, ix_
       4. NON-BLIND autoregressive pass over the file with that filter (:350-407, `restore_file_AR`);
       5. undo the normalisation (:409).
 
-    degraded: [L] or [1, L] device tensor at exp.sample_rate (the torchaudio resampling of the reference is outside this
-    build).  Returns (restored [L], estimated_filter [2, K], blind-step prediction [n, segL])."""
+    degraded: [L] or [1, L] device tensor sampled at `fs` (None: already at exp.sample_rate, no conversion).  With `fs` given
+    the reference's rate conversions are part of the flow (babe_amd/resample.py = torchaudio.functional.resample as published),
+    exactly where testing/denoise_and_bwe_tester.py:279-289 has them: with a denoiser, fs -> sample_rate_denoiser before it and
+    sample_rate_denoiser -> exp.sample_rate after it - BOTH only `if fs != sample_rate_denoiser`, as the reference writes it (a
+    file already at the denoiser's rate goes to the model unconverted there too); without one, fs -> exp.sample_rate.
+    Returns (restored [L'] at exp.sample_rate, estimated_filter [2, K], blind-step prediction [n, segL])."""
     import numpy as np
     rng = rng or np.random
     args = sampler.args
     segL = args.exp.audio_len
     d = degraded.reshape(1, -1).float()
+    if fs is not None:
+        from ..resample import resample
     if denoiser is not None:
+        srd = sample_rate_denoiser if sample_rate_denoiser is not None else denoiser._get("sample_rate_denoiser")
+        if fs is not None and fs != srd:
+            d = resample(d, fs, srd)
         d = denoiser.apply_denoiser(d)
+        if fs is not None and fs != srd:
+            d = resample(d, srd, args.exp.sample_rate)
+    elif fs is not None:
+        d = resample(d, fs, args.exp.sample_rate)
     s = d.std(-1)
     d = std * d / s.unsqueeze(-1)
     L = d.shape[-1]

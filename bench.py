@@ -307,16 +307,6 @@ def main():
         return gather_results(clips, fpc, force_collective=True) if (world > 1 or launched) else (clips, fpc)
 
     do_prof = a.profile_steps > 0 and rank == 0
-    # Setup (untimed, before the warm-up steps): the sampler captures the HIP graphs of a configuration on its SECOND call
-    # (the first one runs eagerly and builds every lazily-created table); timed steps then replay them, except the
-    # profiled ones - the measurement hook's HIP events cannot be part of a graph, so those run the eager loop.
-    n_prof_plan = min(a.profile_steps, a.steps) if do_prof else 0
-    graphs_on = bool(getattr(sampler, "GRAPHS", False)) and a.steps > n_prof_plan
-    if graphs_on:
-        for _ in range(2):
-            one_step(0)
-        torch.cuda.synchronize()
-        graphs_on = any("graphs" in v for v in getattr(sampler, "_graphs", {}).values())
     # Warm-up.  The LAST warm-up step also measures every launch with all batch items on ONE stream (kernels serialised,
     # so a launch duration is that kernel alone - the figure a rocprofv3 kernel trace of this command agrees with, since
     # tracing serialises the lanes too); the timed region below runs batch items on two streams and its per-launch
@@ -456,9 +446,8 @@ def main():
                        "parallelism": "clips sharded over %d GPU(s), one process per GPU, %s" % (
                            world, "no collective (single rank, no launcher)" if not (world > 1 or launched) else
                            "%s all_gather at end of step" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())),
-                       "hip_graphs": ("timed steps replay per-(lane, Heun step) HIP graphs captured during setup; the %d "
-                                      "profiled step(s) run the eager loop (HIP events around every launch)" % n_prof
-                                      if graphs_on else "off (eager launch loop)"),
+                       "hip_graphs": "none: eager launch loop, no host sync inside a step (the opt-in graph replay of rounds 2-4 "
+                                     "measured 2.129 vs 2.140 audio-sec/s on this command and was removed in round 5)",
                        "headline": a.T == 35 and a.precision == "f32" and C_ == 1},
             "per_gpu_realtime_factor": round(value / world, 5),
             "output_finite": finite,

@@ -162,6 +162,14 @@ int babe_resample(const float* in, long in_bs, long in_cs, float* out, long out_
 int babe_resample_res(const float* in, long in_bs, long in_cs, const float* res, long res_bs, long res_cs, float* out,
                       long out_bs, long out_cs, int B, int C, int F, int T, int mode, float alpha, float beta, void* stream);
 
+/* ---- sample-rate conversion of the file-level flows: torchaudio.functional.resample as published (Hann-windowed sinc,
+ * lowpass_filter_width 6, rolloff 0.99), testing/blind_bwe_tester.py:410,744,930, testing/denoise_and_bwe_tester.py:282-289.
+ * orig / new_: the two rates divided by their gcd; kernel [new_][2 width + orig] (host-built, babe_amd/resample.py);
+ * krange [new_][2] = first and one-past-last non-zero tap of each phase.  out[b][i new_ + j] = sum_k kernel[j][k] xpad[b][i orig + k]
+ * with xpad = x padded by (width, width + orig) zeros; L_out = ceil(new_ L_in / orig). */
+int babe_resample_sinc(const float* x, long x_bs, float* out, long out_bs, int B, long L_in, long L_out, const float* kernel,
+                       const int* krange, int orig, int new_, int width, void* stream);
+
 /* ---- the whole UNet body from one call: networks/cqtdiff+.py:746-839 (forward), ResnetBlock :452-493, and its input-VJP
  * (the autograd pass of testing/blind_bwe_sampler.py:120).  csrc/unet_engine.hip sequences the op-level functions of this header
  * exactly as babe_amd/networks/unet_engine.py does (bit-identical results); fp32 convs.  All device memory is the caller's. */

@@ -213,7 +213,11 @@ def test_config5_geometry_denoise_then_bwe_bf16_runs():
     dnet = dn.MultiStage_denoise(cfg)
     dnet.load_state_dict(dn.init_state_dict(cfg, seed=3))
     dnet.to("cuda")
-    pre = DenoiserPrepass(dnet, dict(sample_rate_denoiser=fs, segment_size=5, stft_win_size=1024, stft_hop_size=256,
+    # the denoiser runs at ITS rate, 22.05 kHz (conf/tester/blind_bwe_denoise_brass.yaml:160), the model at 16 kHz
+    # (conf/exp/CocoChorales_16k_8s.yaml:51): the recording goes fs -> 22050 -> denoiser -> 16000 -> BWE as
+    # testing/denoise_and_bwe_tester.py:279-289 does (babe_amd/resample.py)
+    srd = 22050
+    pre = DenoiserPrepass(dnet, dict(sample_rate_denoiser=srd, segment_size=5, stft_win_size=1024, stft_hop_size=256,
                                      num_stages=2), "cuda")
     g = torch.Generator().manual_seed(5)
     t_ax = torch.arange(L) / fs
@@ -221,12 +225,86 @@ def test_config5_geometry_denoise_then_bwe_bf16_runs():
     torch.manual_seed(0)
     np.random.seed(1)
     out, filt, _ = restore_recording_complete(smp, rec.cuda(), n_segments_blindstep=2, ix_start=0, std=0.15, overlap_s=0.25,
-                                              typefilter="fc_A", denoiser=pre)
+                                              typefilter="fc_A", denoiser=pre, fs=fs, sample_rate_denoiser=srd)
     torch.cuda.synchronize()
-    assert out.shape == (L,) and bool(torch.isfinite(out).all())
+    from babe_amd.resample import resample, resampled_length
+    assert out.shape == (resampled_length(resampled_length(L, fs, srd), srd, fs),) and abs(out.shape[0] - L) <= 1
+    assert bool(torch.isfinite(out).all())
     fc, A = filt[0].cpu(), filt[1].cpu()
     assert bool((fc >= 20).all()) and bool((fc <= fs / 2).all()) and bool((fc[1:] >= fc[:-1] + 1 - 1e-3).all())
     assert bool((A <= -1 + 1e-5).all()) and bool((A >= -50 - 1e-5).all()) and bool((A[1:] <= A[:-1] + 1e-5).all())
-    ratio = float(out.std()) / float(pre.apply_denoiser(rec.cuda().unsqueeze(0)).std())
+    ratio = float(out.std()) / float(pre.apply_denoiser(resample(rec.cuda().unsqueeze(0), fs, srd)).std())
     print(f"config-5 flow: output/denoised loudness ratio {ratio:.2f} (random weights), filter fc {fc.tolist()} A {A.tolist()}")
     assert 0.01 < ratio < 100.0                      # (an untrained network + sigma 0.6 start: only boundedness is meaningful)
+
+
+def _config5_flow(T, start_sigma, Ns=(64, 96, 96, 128, 128, 256, 256), precision="bf16", dn_cfg=None, L=480000, fs_file=16000,
+                  seed=5, timing=None):
+    """BASELINE configs[4] on one GPU, at the sizes its YAMLs give: model 16 kHz / audio_len 184184 (conf/exp/
+    CocoChorales_16k_8s.yaml:51-52), sigma_data 0.15, sigma_max 2, rho 9 (conf/tester/blind_bwe_denoise_brass.yaml:58-63),
+    denoiser at 22.05 kHz with the shipped depth 6 / num_tfc 3 (same file, `denoiser:` node), 30 s file."""
+    import time
+    from babe_amd.config import default_args
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.networks import denoiser as dn
+    from babe_amd.networks.cqtdiff_plus import Unet_CQT_oct_with_attention, init_state_dict
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    from babe_amd.testing.denoise import DenoiserPrepass
+    from babe_amd.testing.long_file import restore_recording_complete
+    fs, segL, srd = 16000, 184184, 22050
+    args = default_args(sample_rate=fs, audio_len=segL, Ns=list(Ns), T=T, start_sigma=start_sigma)
+    dpar = args.tester.diff_params
+    dpar.sigma_data, dpar.sigma_max, dpar.ro, dpar.Schurn = 0.15, 2.0, 9, 5
+    net = Unet_CQT_oct_with_attention(args, "cuda", precision=precision)
+    net.load_state_dict(init_state_dict(list(Ns), args.network.num_dils, seed=1, gate_scale=1.0))
+    smp = BlindSampler(ResidualNet(net, 0.3, 0.15), EDM(args), args, noise_device="cuda")
+    cfg = dn_cfg or dict(depth=6, num_tfc=3, num_stages=2, use_SAM=True, use_fencoding=True, f_dim=513)
+    dnet = dn.MultiStage_denoise(cfg)
+    dnet.load_state_dict(dn.init_state_dict(cfg, seed=3))
+    dnet.to("cuda")
+    pre = DenoiserPrepass(dnet, dict(sample_rate_denoiser=srd, segment_size=5, stft_win_size=1024, stft_hop_size=256,
+                                     num_stages=2), "cuda")
+    g = torch.Generator().manual_seed(seed)
+    t_ax = torch.arange(L) / fs_file
+    rec = sum(0.1 / (k + 1) * torch.sin(2 * np.pi * 233.0 * (k + 1) * t_ax) for k in range(6)) + 0.02 * torch.randn(L, generator=g)
+    rec = rec.cuda()
+    runs = 2 if timing is not None else 1
+    for r in range(runs):                                  # (timing: the second run, tables / packed weights / allocator warm)
+        torch.manual_seed(0)
+        np.random.seed(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out, filt, pred = restore_recording_complete(smp, rec, n_segments_blindstep=2, ix_start=0, std=0.15, overlap_s=0.25,
+                                                     typefilter="fc_A", denoiser=pre, fs=fs_file, sample_rate_denoiser=srd)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    if timing is not None:
+        timing["seconds"] = dt
+        timing["audio_seconds"] = L / fs_file
+    return out, filt, pred, pre, rec, net
+
+
+def test_config5_full_width_bf16_at_its_real_size():
+    """configs[4] ONCE at its real size: the FULL-width bf16 network (Ns = [64, 96, 96, 128, 128, 256, 256]) on
+    184184-sample 16 kHz segments with the config's sigma_data 0.15 / sigma_max 2 / rho 9 and its start_sigma 0.6, the full
+    denoiser (depth 6, num_tfc 3) at 22.05 kHz with both rate conversions, blind step on 2 segments, AR pass over the 30 s file
+    (3 segments); T = 2.  No reference output can exist at this size (hours on the CPU, weights unavailable): the checks are the
+    size-independent ones - finite, length rule of the two conversions, loudness bounded, filter inside its constraint set, the
+    bf16 conv kernels actually dispatched."""
+    from babe_amd import _lib
+    from babe_amd.resample import resample, resampled_length
+    _lib.dispatch_counts(reset=True)
+    L, fs = 480000, 16000
+    out, filt, pred, pre, rec, net = _config5_flow(T=2, start_sigma=0.6)
+    counts = _lib.dispatch_counts()
+    assert out.shape == (resampled_length(resampled_length(L, fs, 22050), 22050, fs),) and abs(out.shape[0] - L) <= 1
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(pred).all()) and pred.shape == (2, 184184)
+    fc, A = filt[0].cpu(), filt[1].cpu()
+    assert bool((fc >= 20).all()) and bool((fc <= fs / 2).all()) and bool((fc[1:] >= fc[:-1] + 1 - 1e-3).all())
+    assert bool((A <= -1 + 1e-5).all()) and bool((A >= -50 - 1e-5).all()) and bool((A[1:] <= A[:-1] + 1e-5).all())
+    assert counts["conv_bf16p"] + counts["conv_bf16"] > 1000 and counts["conv53_wino45"] == 0, counts     # bf16 arithmetic, full width
+    assert counts["denoiser"] > 100, counts
+    den = pre.apply_denoiser(resample(rec.unsqueeze(0), fs, 22050))
+    ratio = float(out.std()) / float(den.std())
+    print(f"config-5 full-size flow: output/denoised loudness ratio {ratio:.3g} (random weights), fc {fc.tolist()} A {A.tolist()}")
+    assert 1e-3 < ratio < 1e3

@@ -106,7 +106,20 @@ def main():
     wA, A = run(sampler, y[:1], names)                                             # (A) one segment alone
     del sampler._use_lanes
     wB, B = run(sampler, y, names)                                                 # (B) the benchmark's step, two lanes
-    nlB = int(B["lane"].max()) + 1
+    # streams of (B): the caller's stream (STFT of the observation, first noise, final cross-fade: a handful of launches) and
+    # the two lane streams.  The analysis below is about the two lanes; the caller's records are reported and set aside.
+    cnt = np.bincount(B["lane"])
+    keep = np.argsort(-cnt)[:2]
+    side = ~np.isin(B["lane"], keep)
+    if side.any():
+        print(f"# (B): {int(side.sum())} launches ({((B['t1_ms'] - B['t0_ms'])[side]).sum() * 1e-3:.4f} s) on the caller's stream set aside")
+    remap = {int(k): i for i, k in enumerate(sorted(keep))}
+    B = {k: v[~side] for k, v in B.items()}
+    B["lane"] = np.array([remap[int(v)] for v in B["lane"]], np.int32)
+    cntA = np.bincount(A["lane"])
+    sideA = A["lane"] != int(np.argmax(cntA))
+    A = {k: v[~sideA] for k, v in A.items()}
+    nlB = 2
     print(f"# T = {a.T}; (A) one segment alone: wall {wA:.3f} s, {len(A['slot'])} launches;  (B) two lanes: wall {wB:.3f} s, "
           f"{len(B['slot'])} launches on {nlB} streams  ->  {10.0 / wB:.3f} audio-sec/s for this step (HIP events around every "
           f"launch cost a few %: the unprofiled step is faster)")
