@@ -22,12 +22,20 @@
 #include "common.h"
 #include "../../include/babe_hip.h"
 #include "prof.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int FC = 8;            // columns per workgroup
-constexpr int FCP = 9;           // padded row length of the LDS images (float2): conflict-free along rows and along columns
-constexpr int FNT = 512;          // 8 waves: one workgroup per CU (98 KB of LDS at N = 644), two waves per SIMD hide the LDS latency
+// Round 5: 7 columns per workgroup, row pitch 7 float2 (odd: conflict-free along rows and along columns without a pad element).
+// Rounds 3-4 ran 8 columns at pitch 9: two 46 KB images + the twiddle table = 98 KB at N = 644 - ONE workgroup per CU, each a
+// chain of dependent Stockham passes (~12 us) with nothing beside it to hide them (0.73 TB/s at B = 32).  At 7
+// columns the images are 2 x 36 KB (77 KB with the table): TWO workgroups per CU for every batch size, the same arithmetic per
+// column in the same order (a column's transform never depended on its neighbours: bit-identical spectra), 644 = 7 * 92 tiles
+// without a remainder.  Global rows are read / written in 28-byte pieces instead of 32-byte ones; the four-to-five tiles that
+// share a 128-byte line still go to one XCD.
+constexpr int FC = 7;            // columns per workgroup
+constexpr int FCP = 7;           // row pitch of the LDS images (float2)
+constexpr int FNT = 512;         // 8 waves per workgroup, two workgroups per CU
 
 struct ColFFTArgs {
     const float* in_re;
@@ -43,6 +51,11 @@ struct ColFFTArgs {
     const float2* big_tw;        // nullptr or [N1][N2] exp(-2 pi i k1 n2 / L)
     int tw_ld, tw_mode;          // 1: tw[row * tw_ld + col], 2: tw[col * tw_ld + row]
     int tiles;
+    // Real-input forms of the FORWARD transform (round 5; both halve a stage's work and bytes):
+    int pack_real;               // stage 1: the tile's 2 FC real columns travel as FC complex ones (a + i b), unpacked at the store
+    int half_rows;               // stage 1: only rows k <= N/2 of the (Hermitian) column spectra are written
+    int mirror_cols;             // stage 2: N1 (0 = off): columns k1 <= N1/2 are transformed; column N1 - k1 is written as the
+                                 // conjugate of rows N - 1 - k2 of column k1 (X[L - k] = conj X[k])
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -111,7 +124,7 @@ __device__ __forceinline__ void stockham_pass(const float2* __restrict__ src, fl
     const int tstride = N / (Ns * R);
     const float inv_ns = 1.f / (float)Ns;                 // (j + 0.5) / Ns truncated is exact for j < 2^22: no integer division
     for (int item = threadIdx.x; item < NR * FC; item += FNT) {
-        const int c = item & (FC - 1), j = item >> 3;
+        const int j = item / FC, c = item - j * FC;
         const int blk = (int)(((float)j + 0.5f) * inv_ns), k = j - blk * Ns;
         float2 v[R];
 #pragma unroll
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(FNT) void colfft_kernel(ColFFTArgs a) {
     const int q = wg >> 3, x = wg & 7;
     const int tile = ((q >> 2) * 8 + x) * 4 + (q & 3);   // (grid padded to a multiple of 32: a bijection onto [0, padded))
     if (tile >= a.tiles) return;                            // surplus tiles of the padding (whole workgroup)
-    const int col0 = tile * FC;
+    const int col0 = tile * (a.pack_real ? 2 * FC : FC);
     const int N = a.N;
     // (the table's loads are issued first and stored after the tile's first loads have been issued: one DRAM latency, not two)
     float2 wreg[3];
@@ -159,6 +172,45 @@ __global__ __launch_bounds__(FNT) void colfft_kernel(ColFFTArgs a) {
     {
         const float* re = a.in_re + (long)b * a.in_bs;
         const float* im = a.in_im ? a.in_im + (long)b * a.in_bs : nullptr;
+        if (INV && a.pack_real) {
+            // Transpose of the forward unpack (last stage of the transposed transform: two REAL output columns per complex
+            // inverse FFT).  Rows k <= N/2 of the two columns' spectra Za, Zb are given; W = Ha + i Hb with the Hermitian halves
+            // Ha[k] = Za[k] / 2, Ha[N - k] = conj(Za[k]) / 2 (0 < k < N/2), Ha[0] = Re Za[0], Ha[N/2] = Re Za[N/2]: then
+            // IDFT(W) = a' + i b', the two real outputs.
+            if (threadIdx.x < (unsigned)N) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (threadIdx.x + u * FNT < N) wl[threadIdx.x + u * FNT] = wreg[u];
+            }
+            const int Nh = N / 2 + 1;
+            for (int base = threadIdx.x; base < Nh * FC; base += 2 * FNT) {
+                float ar[2], ai[2], br[2], bi[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int item = base + u * FNT;
+                    const int r = item / FC, c = item - r * FC;
+                    const int ca = col0 + 2 * c;
+                    const bool oka = item < Nh * FC && r < a.in_rows && ca < a.ncols, okb = oka && ca + 1 < a.ncols;
+                    const long o = oka ? (long)r * a.in_ld + ca : 0;
+                    ar[u] = oka ? re[o] : 0.f;
+                    ai[u] = oka ? im[o] : 0.f;
+                    br[u] = okb ? re[o + 1] : 0.f;
+                    bi[u] = okb ? im[o + 1] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int item = base + u * FNT;
+                    if (item >= Nh * FC) continue;
+                    const int r = item / FC, c = item - r * FC;
+                    if (r == 0 || 2 * r == N) {
+                        buf0[r * FCP + c] = make_float2(ar[u], br[u]);
+                    } else {
+                        buf0[r * FCP + c] = make_float2(0.5f * (ar[u] - bi[u]), 0.5f * (ai[u] + br[u]));
+                        buf0[(N - r) * FCP + c] = make_float2(0.5f * (ar[u] + bi[u]), 0.5f * (br[u] - ai[u]));
+                    }
+                }
+            }
+        } else
         for (int base = threadIdx.x; base < N * FC; base += 4 * FNT) {
             float vr[4], vi[4];
             if (base == (int)threadIdx.x) {
@@ -169,16 +221,36 @@ __global__ __launch_bounds__(FNT) void colfft_kernel(ColFFTArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int item = base + u * FNT;
-                const int c = item & (FC - 1), r = item >> 3;
-                const bool ok = item < N * FC && r < a.in_rows && col0 + c < a.ncols;
+                const int r = item / FC, c = item - r * FC;
+                if (!INV && a.pack_real) {
+                    // two neighbouring REAL columns as one complex column: z = x[:, 2c] + i x[:, 2c + 1]
+                    const int ca = col0 + 2 * c;
+                    const bool oka = item < N * FC && r < a.in_rows && ca < a.ncols, okb = oka && ca + 1 < a.ncols;
+                    const long o = oka ? (long)r * a.in_ld + ca : 0;
+                    vr[u] = oka ? re[o] : 0.f;
+                    vi[u] = okb ? re[o + 1] : 0.f;
+                    continue;
+                }
+                const bool okc = item < N * FC && col0 + c < a.ncols;
+                const bool ok = okc && r < a.in_rows;
                 const long o = ok ? (long)r * a.in_ld + col0 + c : 0;
                 vr[u] = ok ? re[o] : 0.f;
                 vi[u] = (ok && im) ? im[o] : 0.f;
+                if (INV && a.mirror_cols) {
+                    // transpose of the forward mirror store: row r >= N - in_rows of column k1 also receives
+                    // conj(spec[N - 1 - r][N1 - k1]) (columns the transformed half does not hold itself)
+                    const int col = col0 + c, mc = a.mirror_cols - col, q = N - 1 - r;
+                    if (okc && q < a.in_rows && col >= 1 && mc >= a.mirror_cols / 2 + 1) {
+                        const long om = (long)q * a.in_ld + mc;
+                        vr[u] += re[om];
+                        vi[u] -= im[om];
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int item = base + u * FNT;
-                if (item < N * FC) buf0[(item >> 3) * FCP + (item & (FC - 1))] = make_float2(vr[u], vi[u]);
+                if (item < N * FC) buf0[(item / FC) * FCP + (item % FC)] = make_float2(vr[u], vi[u]);
             }
         }
     }
@@ -206,7 +278,40 @@ __global__ __launch_bounds__(FNT) void colfft_kernel(ColFFTArgs a) {
     // ---- store (+ the four-step twiddle)
     float* ore = a.out_re + (long)b * a.out_bs;
     float* oim = a.out_im ? a.out_im + (long)b * a.out_bs : nullptr;
-    if (a.out_transposed) {
+    if (!INV && a.pack_real) {
+        // Unpack Z = FFT(a + i b):  A[k] = (Z[k] + conj Z[N - k]) / 2,  B[k] = -i (Z[k] - conj Z[N - k]) / 2, then the four-step
+        // twiddle, written transposed out[col][k] for the tile's 2 FC real columns; rows k <= N / 2 only with half_rows (the
+        // rest is the conjugate mirror and the second stage does not read it).  One index space item = c2 Nh + k, k fastest.
+        const int Nh = a.half_rows ? N / 2 + 1 : N;
+        const float inv_nh = 1.f / (float)Nh;
+        for (int base = threadIdx.x; base < Nh * 2 * FC; base += 4 * FNT) {
+            float2 tw[4];
+            int rr[4], cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int item = base + u * FNT;
+                cc[u] = (int)(((float)item + 0.5f) * inv_nh);
+                rr[u] = item - cc[u] * Nh;
+                tw[u] = make_float2(1.f, 0.f);
+                if (a.big_tw && item < Nh * 2 * FC && col0 + cc[u] < a.ncols)
+                    tw[u] = a.tw_mode == 1 ? a.big_tw[(long)rr[u] * a.tw_ld + col0 + cc[u]] : a.big_tw[(long)(col0 + cc[u]) * a.tw_ld + rr[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int item = base + u * FNT;
+                if (item >= Nh * 2 * FC || col0 + cc[u] >= a.ncols) continue;
+                const int c = cc[u] >> 1;
+                const int rm = rr[u] == 0 ? 0 : N - rr[u];
+                const float2 z1 = src[rr[u] * FCP + c], z2 = src[rm * FCP + c];
+                float2 v = (cc[u] & 1) ? make_float2(0.5f * (z1.y + z2.y), 0.5f * (z2.x - z1.x))
+                                       : make_float2(0.5f * (z1.x + z2.x), 0.5f * (z1.y - z2.y));
+                if (a.big_tw) v = cmul(v, tw[u]);
+                const long o = (long)(col0 + cc[u]) * a.out_ld + rr[u];
+                ore[o] = v.x;
+                if (oim) oim[o] = v.y;
+            }
+        }
+    } else if (a.out_transposed) {
         // out[col][row]: rows fastest across the threads (contiguous runs of N floats per column and plane); ONE index space
         // item = c N + r over the tile, four items per thread and round, their twiddle loads issued together (a loop over the
         // 8 columns paid a DRAM latency per column)
@@ -237,10 +342,19 @@ __global__ __launch_bounds__(FNT) void colfft_kernel(ColFFTArgs a) {
                 if (oim) oim[o] = v.y;
             }
         }
+    } else if (INV && a.pack_real) {
+        // the two real outputs of a packed inverse transform: real part -> column 2c, imaginary part -> column 2c + 1
+        const int rows = a.out_rows < N ? a.out_rows : N;
+        for (int item = threadIdx.x; item < rows * 2 * FC; item += FNT) {
+            const int r = item / (2 * FC), c2 = item - r * (2 * FC);
+            if (col0 + c2 >= a.ncols) continue;
+            const float2 v = src[r * FCP + (c2 >> 1)];
+            ore[(long)r * a.out_ld + col0 + c2] = (c2 & 1) ? v.y : v.x;
+        }
     } else {
         const int rows = a.out_rows < N ? a.out_rows : N;
         for (int item = threadIdx.x; item < rows * FC; item += FNT) {
-            const int c = item & (FC - 1), r = item >> 3;
+            const int r = item / FC, c = item - r * FC;
             if (col0 + c >= a.ncols) continue;
             float2 v = src[r * FCP + c];
             if (a.big_tw) {
@@ -251,6 +365,20 @@ __global__ __launch_bounds__(FNT) void colfft_kernel(ColFFTArgs a) {
             const long o = (long)r * a.out_ld + col0 + c;
             ore[o] = v.x;
             if (oim) oim[o] = v.y;
+        }
+        if (!INV && a.mirror_cols) {
+            // Hermitian half: X[(N1 - k1) + N1 k2'] = conj X[k1 + N1 (N - 1 - k2')] - rows N - rows .. N - 1 of this tile's columns
+            // k1 >= 1 become rows rows - 1 .. 0 of columns N1 - k1 (only columns the transformed half does not hold itself)
+            const int N1 = a.mirror_cols, nh1 = N1 / 2 + 1;
+            for (int item = threadIdx.x; item < rows * FC; item += FNT) {
+                const int q = item / FC, c = item - q * FC;          // q: target row k2'
+                const int col = col0 + c, mc = N1 - col;
+                if (col < 1 || col >= a.ncols || mc < nh1) continue;
+                const float2 v = src[(N - 1 - q) * FCP + c];
+                const long o = (long)q * a.out_ld + mc;
+                ore[o] = v.x;
+                if (oim) oim[o] = -v.y;
+            }
         }
     }
 }
@@ -306,7 +434,13 @@ extern "C" int babe_rfft_mixed(const float* x_in, float* spec_out, const float* 
         a1.N = N1; a1.ncols = N2; a1.nrad = nrad1;
         for (int i = 0; i < nrad1; ++i) a1.rad[i] = rad1[i];
         a1.wN = reinterpret_cast<const float2*>(w1); a1.big_tw = reinterpret_cast<const float2*>(tw); a1.tw_ld = N2; a1.tw_mode = 1;
-        a1.tiles = cdiv(N2, FC);
+        // real input: two columns per complex transform, and only rows k1 <= N1/2 of the intermediate are produced; the second
+        // stage transforms those columns and writes the others as conjugate mirrors (half the butterflies and a third less
+        // traffic per transform).  BABE_FFT_REAL=0: the complex form of round 4 on both stages (A/B switch).
+        static const char* ovr = getenv("BABE_FFT_REAL");
+        const bool real_form = !(ovr && ovr[0] == '0');
+        a1.pack_real = real_form; a1.half_rows = real_form;
+        a1.tiles = real_form ? cdiv(N2, 2 * FC) : cdiv(N2, FC);
         // stage 2: At[n2][k1] -> spec[k2][k1], k2 < K2
         a2.in_re = work; a2.in_im = work + L; a2.in_bs = 2 * L; a2.in_ld = N1; a2.in_rows = N2;
         a2.out_re = spec_out; a2.out_im = spec_out + (long)K2 * N1; a2.out_bs = 2L * K2 * N1; a2.out_ld = N1; a2.out_rows = K2;
@@ -314,6 +448,11 @@ extern "C" int babe_rfft_mixed(const float* x_in, float* spec_out, const float* 
         a2.N = N2; a2.ncols = N1; a2.nrad = nrad2;
         for (int i = 0; i < nrad2; ++i) a2.rad[i] = rad2[i];
         a2.wN = reinterpret_cast<const float2*>(w2); a2.big_tw = nullptr; a2.tiles = cdiv(N1, FC);
+        if (real_form) {
+            a2.ncols = N1 / 2 + 1;
+            a2.mirror_cols = N1;
+            a2.tiles = cdiv(a2.ncols, FC);
+        }
         if (int e = launch(a1, B, 0, s)) return e;
         if (int e = launch(a2, B, 0, s)) return e;
     } else {
@@ -325,12 +464,26 @@ extern "C" int babe_rfft_mixed(const float* x_in, float* spec_out, const float* 
         for (int i = 0; i < nrad2; ++i) a1.rad[i] = rad2[i];
         a1.wN = reinterpret_cast<const float2*>(w2); a1.big_tw = reinterpret_cast<const float2*>(tw); a1.tw_ld = N2; a1.tw_mode = 2;
         a1.tiles = cdiv(N1, FC);
+        // the exact transposes of the real-input forms of direction 0 (same switch): step 1 transforms the columns k1 <= N1/2
+        // with the mirrored half of the spectrum added in conjugated, step 2 produces two real columns per inverse transform
+        static const char* ovr = getenv("BABE_FFT_REAL");
+        const bool real_form = !(ovr && ovr[0] == '0');
+        if (real_form) {
+            a1.ncols = N1 / 2 + 1;
+            a1.mirror_cols = N1;
+            a1.tiles = cdiv(a1.ncols, FC);
+        }
         // step 2: Z[k1][n2] -> x[n1][n2] (real part)
         a2.in_re = work; a2.in_im = work + L; a2.in_bs = 2 * L; a2.in_ld = N2; a2.in_rows = N1;
         a2.out_re = x_out; a2.out_im = nullptr; a2.out_bs = L; a2.out_ld = N2; a2.out_rows = N1; a2.out_transposed = 0;
         a2.N = N1; a2.ncols = N2; a2.nrad = nrad1;
         for (int i = 0; i < nrad1; ++i) a2.rad[i] = rad1[i];
         a2.wN = reinterpret_cast<const float2*>(w1); a2.big_tw = nullptr; a2.tiles = cdiv(N2, FC);
+        if (real_form) {
+            a2.pack_real = 1;
+            a2.in_rows = N1 / 2 + 1;
+            a2.tiles = cdiv(N2, 2 * FC);
+        }
         if (int e = launch(a1, B, 1, s)) return e;
         if (int e = launch(a2, B, 1, s)) return e;
     }
