@@ -168,7 +168,7 @@ def cpu_baseline():
     return out
 
 
-PMC_TRAFFIC_FILE = "r04_conv_traffic.json"
+PMC_TRAFFIC_FILE = "r05_conv_traffic.json"
 
 
 def conv_traffic(precision):
