@@ -11,20 +11,20 @@ SOURCES = ["misc.hip", "conv.hip", "conv11p.hip", "conv_fewco.hip", "conv_bf16.h
 
 # Every source is built WITHOUT packed-fp32 instructions: no SLP vectoriser (-fno-slp-vectorize) and the target feature
 # packed-fp32-ops switched off (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32 are never selected, also not for
-# explicit float2 / float4 vector arithmetic).  Two reasons, both measured in round 3:
+# explicit float2 / float4 vector arithmetic).  Two reasons:
 #  * speed of the fp32-MFMA kernels: next to fp32 MFMAs every vector instruction costs matrix-pipe time
 #    (tools/mfma_valu_coexec.hip: a v_pk_fma_f32 costs 1.6x a v_fma_f32, a v_mov as much as a v_fma), and the vectoriser pays
 #    for its packed arithmetic with register moves: conv_wino45 207 instead of 245 vector instructions per two K-slabs;
-#  * CORRECTNESS next to the bf16 conv: kernels that contain packed-fp32 instructions (conv_fewco, the FFT's twiddle /
-#    transpose, epilogues with float4 arithmetic, ...) return slightly wrong sums - one of a thread's four outputs, half of
-#    the lanes, errors the size of a few product terms - when they run on a second stream beside conv_bf16p
-#    (v_mfma_f32_32x32x16_bf16): 25-30 of 30 runs in tools/coresidency_probe.py, about one two-lane bf16 sampler run in four.
-#    Alone they are exact.  Without the vectoriser only: 0 of 30 in the probe, 2 of 12 sampler runs still differ (explicit
-#    vector arithmetic still becomes v_pk_*); with packed-fp32-ops off as well - not one v_pk_ instruction in the library -
-#    0 of 16 two-lane bf16 sampler runs (tools/bf16_lanes_soak.py) and 0 of 30 in every pairing of the probe.  Neither an LDS
-#    canary nor hand-written v_pk_* chains beside the bf16 conv reproduce it (tools/lds_canary.hip), so the trigger is
-#    narrower than "any packed instruction" - but with none in the library the question does not arise.
-#    Whole-job throughput is unchanged (f32 1.794 vs 1.797, same box); bf16 runs its clips on two lanes again: 3.18 -> 3.68.
+#  * CORRECTNESS next to the bf16 conv.  Round 3 saw kernels built with hipcc's defaults (conv_fewco, the FFT's twiddle /
+#    transpose, epilogues with float4 arithmetic) return wrong sums when they ran on a second stream beside conv_bf16p.  Round 4
+#    reduced it to ONE instruction form and a 60-line reproducer with no library in it (tools/erratum/pk_opsel_min.hip,
+#    profiles/r04_coresidency_repro.txt): v_pk_{mul,add,fma}_f32 with op_sel:[0,1] - the low half of the result reads the HIGH
+#    word of src1 - computes as if that word were 0 while waves of ANOTHER kernel execute bf16 MFMA on the same CU; plain packed
+#    forms, op_sel:[1,0] and op_sel_hi:[1,0] were never wrong.  hipcc emits exactly that selector when it vectorises
+#    `w[k] * float4`.  With no packed-fp32 instruction in the library the question does not arise for its own kernels
+#    (tests/test_no_packed_fp32.py disassembles the library and keeps it that way); kernels of OTHER code running beside the
+#    bf16 conv are the reason a bf16 network keeps one stream by default (networks/cqtdiff_plus.py).
+#    Whole-job throughput is unchanged by the flags (f32 1.794 vs 1.797 audio-sec/s, same box).
 # (The host pass prints "'-packed-fp32-ops' is not a recognized feature for this target (ignoring feature)": filtered below.)
 COMMON_FLAGS = ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA_FLAGS = {}

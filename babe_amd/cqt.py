@@ -335,7 +335,7 @@ class CQT_nsgt:
         for k in ("c", "M", "woff", "log2T", "oct", "binoct", "wg_first", "wg_count", "wg_rec", "band_rec"):
             setattr(s, k, ptr(self._tabs[k]))
         s.nwg = self.nwg
-        s.abl = 0                                         # (ablation builds only: tools/abl_build.sh -DBABE_CQT_ABL)
+        s.abl = 0                                         # (ablation builds only: tools/ab/abl_build.sh -DBABE_CQT_ABL)
         s.max_wg_count, (s.min_log2T, s.max_log2T) = self._wg_max, self._l2_range
         s.tw4096 = ptr(self.tw4096)
         s.nocts, s.binsoct = self.numocts, self.binsoct

@@ -33,7 +33,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ABL: compile-time ablation bits for profiling builds (tools/abl_build.sh conv_wino45 <mask>): 1 no activation loads,
+// ABL: compile-time ablation bits for profiling builds (tools/ab/abl_build.sh conv_wino45 <mask>): 1 no activation loads,
 // 2 no MFMA, 4 no operand LDS reads, 8 no input transform / LDS stores, 16 no barrier, 32 no weight DMA, 64 every slab
 // loads channel 0 (cache-resident loads: same instructions, no memory-side traffic).  NB: with the loads or the transform
 // removed hipcc also removes whatever became dead (ablation 1 drops the transform arithmetic too) (cache-resident loads: same instructions, no memory-side traffic)

@@ -198,7 +198,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
     supports_lanes = True
     # precision='bf16' and clip lanes.  Kernels that contain the packed-fp32 form v_pk_{mul,add,fma}_f32 ... op_sel:[0,1] read the
     # HIGH word of their second source as 0 while another kernel's waves execute bf16 MFMA on the same CU (reduced in round 4:
-    # tools/pk_opsel_min.hip, DESIGN.md "Co-residency finding").  THIS library contains no packed-fp32 instruction
+    # tools/erratum/pk_opsel_min.hip, DESIGN.md "Co-residency finding").  THIS library contains no packed-fp32 instruction
     # (babe_amd/build.py, tests/test_no_packed_fp32.py), but what ELSE runs beside conv_bf16p is outside its control: PyTorch's own
     # kernels (device-side noise: bench.py's noise_device='cuda'), RCCL, a second process on the same GPU (two ranks on one
     # device), a host application's hipcc-default kernels.  So a bf16 network keeps its batch items on ONE stream by default;

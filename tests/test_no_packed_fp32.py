@@ -1,7 +1,7 @@
 """The HIP library must not contain packed-fp32 instructions (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32, v_pk_mov_b32) nor any
 instruction with an op_sel modifier: on the MI355X pool `v_pk_{mul,add,fma}_f32 ... op_sel:[0,1]` (low result half reads the HIGH
 word of src1) computes as if that word were 0 while another kernel's waves run bf16 MFMA on the same CU - reduced in round 4 to
-the 60-line self-contained tools/pk_opsel_min.hip (profiles/r04_coresidency_repro.txt).  The library was affected
+the 60-line self-contained tools/erratum/pk_opsel_min.hip (profiles/r04_coresidency_repro.txt).  The library was affected
 in round 3 when hipcc's defaults put such instructions into conv_fewco / the CQT kernels; the build flags
 (babe_amd/build.py COMMON_FLAGS) remove them and this test keeps it that way.  Disassembles the device code of the built library
 - no GPU needed."""

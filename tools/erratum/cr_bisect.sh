@@ -5,6 +5,6 @@ mkdir -p gpurun_out/r4cr
 export PARTNERS="${PARTNERS:-bf16p units 64ch,sgu only 64ch,bf16p fwd 64ch,bf16p fwd 256ch}"
 for v in "$@"; do
   echo "== $v"
-  BABE_HIP_LIB=$PWD/tools/abl_out/$v/libbabe_hip.so BABE_FFT_MIXED=0 timeout 300 python3 tools/coresidency_probe.py 2>&1 | grep victim
+  BABE_HIP_LIB=$PWD/tools/abl_out/$v/libbabe_hip.so BABE_FFT_MIXED=0 timeout 300 python3 tools/erratum/coresidency_probe.py 2>&1 | grep victim
 done > gpurun_out/r4cr/bisect_${TAG:-1}.txt
 cat gpurun_out/r4cr/bisect_${TAG:-1}.txt
