@@ -146,9 +146,24 @@ struct CqPass {
             }
         }
     }
+    // number of table entries a butterfly of this pass loads: W^(k t) for t = 1, 2, 4, 8 below R
+    static constexpr int NTW = R >= 16 ? 4 : (R >= 8 ? 3 : (R >= 4 ? 2 : 1));
+    // The table entries of this pass depend on the thread only (k = j mod Ns): they are loaded BEFORE the first butterflies of
+    // the transform (round 5) - issued right after the band's input loads, so that their global-memory latency runs behind those
+    // and pass 0 instead of being paid after every inter-pass barrier (hipcc does not move a load across __syncthreads()).
+    static __device__ __forceinline__ void load_tw(f2 (&pre)[CNT * NTW], const f2* __restrict__ tw, int u) {
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) {
+            const int j = u + c * TB;
+            constexpr int stride = 4096 / (Ns * R);
+            const int q1 = (j & (Ns - 1)) * stride;               // < 4096 / R
+#pragma unroll
+            for (int e = 0; e < NTW; ++e) pre[c * NTW + e] = cq_tw(tw, q1 << e);
+        }
+    }
     // LDS -> registers, twiddles, butterflies (P >= 1)
     template <int S>
-    static __device__ __forceinline__ void gather_bfly(f2* v, const f2* a, const f2* __restrict__ tw, int base, int u) {
+    static __device__ __forceinline__ void gather_bfly(f2* v, const f2* a, const f2 (&pre)[CNT * NTW], int base, int u) {
 #pragma unroll
         for (int c = 0; c < CNT; ++c) {
             const int j = u + c * TB;
@@ -158,14 +173,12 @@ struct CqPass {
 #pragma unroll
             for (int t = 0; t < R; ++t) x[t] = ap[t * (NR + NR / 16)];
             // W^(k t): t = 1, 2, 4, 8 from the table, the rest as products of two of those (<= 3 roundings)
-            constexpr int stride = 4096 / (Ns * R);
-            const int q1 = (j & (Ns - 1)) * stride;               // < 4096 / R
             // (table = exp(-2 pi i q/4096): S < 0 multiplies by it, S > 0 by its conjugate)
             f2 w[R];
-            w[1] = cq_tw(tw, q1);
-            if constexpr (R >= 4) w[2] = cq_tw(tw, 2 * q1);
-            if constexpr (R >= 8) w[4] = cq_tw(tw, 4 * q1);
-            if constexpr (R >= 16) w[8] = cq_tw(tw, 8 * q1);
+            w[1] = pre[c * NTW];
+            if constexpr (R >= 4) w[2] = pre[c * NTW + 1];
+            if constexpr (R >= 8) w[4] = pre[c * NTW + 2];
+            if constexpr (R >= 16) w[8] = pre[c * NTW + 3];
 #pragma unroll
             for (int t = 3; t < R; ++t) {
                 const int hb = t >= 8 ? 8 : (t >= 4 ? 4 : 2);      // highest power of two in t
@@ -185,18 +198,21 @@ template <int LT, int S>
 __device__ __forceinline__ void cq_band_fft_regs(f2* v, f2* a, const f2* __restrict__ tw, int base, int u, bool active) {
     constexpr int NP = cq_npass(LT);
     using P0 = CqPass<LT, 0>;
+    using P1 = CqPass<LT, (NP >= 2 ? 1 : 0)>;
+    using P2 = CqPass<LT, (NP >= 3 ? 2 : 0)>;
+    f2 tw1[P1::CNT * P1::NTW], tw2[P2::CNT * P2::NTW];
+    if constexpr (NP >= 2) P1::load_tw(tw1, tw, u);
+    if constexpr (NP >= 3) P2::load_tw(tw2, tw, u);
     cq_fft<P0::R, S>(v);
     if constexpr (NP >= 2) {
-        using P1 = CqPass<LT, 1>;
         if (active) P0::scatter(v, a, base, u);
         __syncthreads();
-        if (active) P1::template gather_bfly<S>(v, a, tw, base, u);
+        if (active) P1::template gather_bfly<S>(v, a, tw1, base, u);
         if constexpr (NP >= 3) {
-            using P2 = CqPass<LT, 2>;
             __syncthreads();
             if (active) P1::scatter(v, a, base, u);
             __syncthreads();
-            if (active) P2::template gather_bfly<S>(v, a, tw, base, u);
+            if (active) P2::template gather_bfly<S>(v, a, tw2, base, u);
         }
     }
 }
