@@ -48,6 +48,9 @@ _SIGS = {
     "babe_conv2d_wino45": [C.POINTER(ConvArgs), _P, _P],
     "babe_conv2d_wino45_supported": [C.POINTER(ConvArgs)],
     "babe_conv2d_wino45_preferred": [C.POINTER(ConvArgs)],
+    "babe_conv2d_wino85": [C.POINTER(ConvArgs), _P, _P],
+    "babe_conv2d_wino85_supported": [C.POINTER(ConvArgs)],
+    "babe_conv2d_wino85_preferred": [C.POINTER(ConvArgs)],
     "babe_conv_pack_weights_wino45": [_P, _P, _I, _I, _I, _I, _I, _P],
     "babe_conv_pack_weights_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "babe_gn_partial": [_P, _P, _I, _I, _L, _I, _P],
@@ -88,6 +91,9 @@ def lib():
         L.babe_conv_packed_size_wino4.argtypes = [_I, _I, _I, _I]
         L.babe_conv_packed_size_wino45.restype = C.c_long
         L.babe_conv_packed_size_wino45.argtypes = [_I, _I, _I]
+        L.babe_conv_packed_size_wino85.restype = C.c_long
+        L.babe_conv_packed_size_wino85.argtypes = [_I, _I, _I]
+        L.babe_conv_pack_weights_wino85.argtypes = [_P, _P, _I, _I, _I, _I, _I, _P]
         L.babe_conv_packed_size_bf16.restype = C.c_long
         L.babe_conv_packed_size_bf16.argtypes = [_I, _I, _I, _I, _I, _I]
         for name, sig in _SIGS.items():

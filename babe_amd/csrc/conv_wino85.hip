@@ -1,0 +1,522 @@
+// EXPERIMENTAL (round 5, opt-in: BABE_CONV_F45=1): nested Winograd F(4,5) along FREQUENCY x F(4,3) along TIME for the
+// frequency-dilated (5,3) Conv2d (networks/cqtdiff+.py:79-88, 433-436), fp32 MFMA.  A unit = 4 output rows of one residue class
+// (f, f + d, f + 2d, f + 3d) x 4 time steps from an 8-row x 6-sample patch: 8 x 6 = 48 products per (ci, co) per 16 outputs =
+// 3.0 per output (conv_wino45.hip: 4.5).  Interpolation points 0, +-1, +-2, +-1/2, inf along frequency (the classic 8-point set),
+// 0, +-1, +-2, inf along time (as conv_wino45.hip).  Paper estimate and rounding study: profiles/r05_wino_f45_estimate.txt.
+//   frequency input transform B^T (rows of the 8-row patch d0..d7):
+//     p0  (0)    = -d0 + 21/4 (d2 - d4) + d6                     p7 (inf) = -d1 + 21/4 (d3 - d5) + d7
+//     p1,2 (+-1) = (d2 - 17/4 d4 + d6) +- (d1 - 17/4 d3 + d5)
+//     p3,4 (+-2) = (1/4 d2 - 5/4 d4 + d6) +- (1/2 d1 - 5/2 d3 + 2 d5)
+//     p5,6 (+-1/2) = (4 d2 - 5 d4 + d6) +- (2 d1 - 5/2 d3 + 1/2 d5)
+//   output A^T (4 rows x 8 phases): [1 1 1 1 1 1 1 0; 0 1 -1 2 -2 1/2 -1/2 0; 0 1 1 4 4 1/4 1/4 0; 0 1 -1 8 -8 1/8 -1/8 1]
+// 48 accumulators per (co, unit) do not fit: TWO PASSES of four frequency phases, A = (p1, p2, p3, p4) - rows 1..6 only - and
+// B = (p5, p6, p0, p7); the partial sums of pass A are carried inside the accumulators of pass B: with C_X = A^T[:, X],
+// M'_B = C_B^-1 C_A M_A:   p5' = 3 m1 + m2 + 10 m3 + 6 m4,  p6' = m1 + 3 m2 + 6 m3 + 10 m4,  p0' = -3 (m1 + m2) - 15 (m3 + m4),
+//                          p7' = 3/4 (m1 - m2) + 15/2 (m3 - m4).
+// Tile: 128 output channels x 16 units (one row quad x 64 steps), 8 waves; wave w owns channel tile w: 4 x 6 = 24 accumulators of
+// v_mfma_f32_16x16x4_f32 (96 registers) = ONE (tile, segment) item per wave.  Pipeline = conv_wino45x_kernel's: wave-private weights
+// by LDS-DMA into a 4-entry ring with counted s_waitcnt, two operand register sets, one barrier per 16-channel super-slab.  A ring
+// entry is a HALF-slot (4 ci x 16 co x 12 of the pass's 24 phases = 3 KB): 8 per super-slab, 24 MFMA groups of 4.
+// Transform: thread = (ci, unit, half): waves 0-3 compute the first phase pair of the pass, waves 4-7 the second, for 4 input
+// channels x 16 units each - coefficients are wave-uniform.
+#include "common.h"
+#include "../../include/babe_hip.h"
+#include "prof.h"
+#include <cstdlib>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct Wino85Geom {
+    int CinP, CoutP, tiles_t, nquads;      // nquads: row quads per residue class
+};
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr unsigned OOBH = 0xC0000000u;
+
+template <bool HAS_ISC>
+__global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, Wino85Geom g, const float* __restrict__ wq) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int KS = 16, KQ = 4, NU = 16, BN = 128;
+    constexpr int XSZ = KS * NU * 6;                    // float4 per activation super-slab (16 ci x 16 units x 24 floats)
+    constexpr int WWV = KQ * 16 * 3;                    // float4 per wave and ring entry (4 ci x 16 co x 12 floats = 3 KB)
+    constexpr int WSL = 8 * WWV;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    f32x4* smem = reinterpret_cast<f32x4*>(smem_f);
+    f32x4* const Xb = smem;                             // X[2]
+    f32x4* const Wb = smem + 2 * XSZ;                   // ring[4][8 waves][4 ci][16 co][3]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.z;
+    const int co0 = blockIdx.y * BN;
+    const int tile_t = blockIdx.x % g.tiles_t;
+    const int Q = blockIdx.x / g.tiles_t;
+    const int t0 = tile_t * 64;
+    const int cls = Q / g.nquads;
+    const int fa = Q < a.dil * g.nquads ? cls + 4 * (Q - cls * g.nquads) * a.dil : a.F + 8 * a.dil;   // first output row
+    const int NS = 2 * (g.CinP / KS);                   // super-slabs
+
+    const float* p1 = a.in + (long)b * a.in_bs;
+    const int cs1 = (int)a.in_cs;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p1, 0, a.Cin * cs1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, 4 * g.CinP * g.CoutP * 48, 0x00020000);
+
+    // ---- staging constants: thread = (ci = 4 (wave & 3) + (lane >> 4), unit = lane & 15); half = wave >> 2
+    const int half = wave >> 2, wq4 = wave & 3;
+    const int s_tu = lane & 15, s_ch = lane >> 4;
+    const int s_t = t0 + 4 * s_tu;
+    const unsigned chb = (unsigned)(s_ch * cs1 * 4);
+    unsigned er[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int fr = fa + (r - 2) * a.dil;
+        const bool ok = fr >= 0 && fr < a.F && s_t < a.T;
+        er[r] = ok ? (unsigned)((fr * a.T + s_t) * 4) + chb : OOBH;
+    }
+    unsigned ehalo = OOBH;
+    {
+        const int hr = lane >> 3, hc = (lane >> 1) & 3, hs = lane & 1;       // 8 rows x 4 channels x 2 sides = 64 lanes
+        const int fr = fa + (hr - 2) * a.dil;
+        const int th = t0 + (hs ? 64 : -1);
+        if (fr >= 0 && fr < a.F && th >= 0 && th < a.T) ehalo = (unsigned)((fr * a.T + th) * 4 + hc * cs1 * 4);
+    }
+    const int hsrc = (2 * s_ch + (s_tu == 15 ? 1 : 0)) * 4;               // bpermute byte index of row 0; row r adds 32
+    const int xlds = ((wq4 * 4 + s_ch) * NU + s_tu) * 6 + half * 3;         // float4 index of this thread's 12 floats
+    // weight DMA (as conv_wino45x_kernel): chunk j of an entry = bytes [1024 j, 1024 j + 1024) of the wave's image [4 ci][16 co][48 B]
+    unsigned wvl[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int o = j * 1024 + lane * 16;
+        const int ci = o / 768;
+        wvl[j] = (unsigned)(ci * g.CoutP * 48 + (o - ci * 768));
+    }
+    const int wstep = KQ * g.CoutP * 48;                // next half-slot in the packed image [pass][ci quad][half][4 ci][CoutP][12]
+    const int sWend = 4 * g.CinP * g.CoutP * 48;
+    int sW = (co0 + wave * 16) * 48;
+    auto w_next = [&]() __attribute__((always_inline)) {
+        sW += wstep;
+        sW = sW < sWend ? sW : sWend;
+    };
+    f32x4* const Ww = Wb + wave * WWV;
+#define Y_DMA(rp, j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(Ww + (rp) * WSL + (j) * 64), 16, wvl[j], sW, 0, 0);
+#define Y_FENCE __builtin_amdgcn_sched_barrier(0);
+#ifdef W85_SAFE
+#define Y_WAITVM(n) asm volatile("s_waitcnt vmcnt(0)");
+#else
+#define Y_WAITVM(n) asm volatile("s_waitcnt vmcnt(" #n ")");
+#endif
+
+    f32x4 xv[8];
+    xv[0] = xv[7] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float xhl = 0.f, xsc = 1.f;
+    float xh[8];
+    int pS = 0;
+    // the patch rows of super-slab (ps, ci0): rows 1..6 always, rows 0 and 7 in pass B only (a wave-uniform branch; pass A's phases
+    // +-1, +-2 do not touch them).  The counted waits below assume the SIX-row form - with the two extra loads of pass B they just
+    // wait for two older operations more, which landed long ago.
+    auto issue_rows = [&](int ps, int ci0, int r0, int r1) __attribute__((always_inline)) {
+        const int so = (ci0 + 4 * wq4) * cs1 * 4;
+#pragma unroll
+        for (int r = 1; r < 7; ++r) {
+            if (r < r0 || r >= r1) continue;
+            xv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[r], so, 0));
+        }
+        if (ps == 1) {
+            if (r0 == 0) xv[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[0], so, 0));
+            if (r1 == 8) xv[7] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[7], so, 0));
+        }
+    };
+    auto issue_halo = [&](int ci0) __attribute__((always_inline)) {
+        const int so = (ci0 + 4 * wq4) * cs1 * 4;
+        xhl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ehalo, so, 0));
+    };
+    auto issue_isc = [&](int ci0) __attribute__((always_inline)) {
+        if (HAS_ISC) xsc = a.in_scale[(long)b * a.Cin + ci0 + 4 * wq4 + s_ch];
+    };
+    auto dpp_shr1 = [](float old, float src) __attribute__((always_inline)) {
+        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+        return old;
+    };
+    auto dpp_shl1 = [](float old, float src) __attribute__((always_inline)) {
+        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+        return old;
+    };
+    auto tt = [](const float (&E)[6], float (&U)[6]) {
+        const float e = E[4] - 4.f * E[2], o = E[3] - 4.f * E[1];
+        const float e2 = E[4] - E[2], o2 = E[3] - E[1];
+        U[0] = 4.f * E[0] + (E[4] - 5.f * E[2]);
+        U[1] = e + o;
+        U[2] = e - o;
+        U[3] = e2 + 2.f * o2;
+        U[4] = e2 - 2.f * o2;
+        U[5] = 4.f * E[1] + (E[5] - 5.f * E[3]);
+    };
+    auto halo_permute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(xh[r]) : "v"(hsrc), "v"(xhl), "n"(32 * r));
+    };
+    // X = c0 d0 + c2 d2 + c4 d4 + d6,  Y = c1 d1 + c3 d3 + c5 d5 + c7 d7,  (Ea, Eb) = (X + al Y, be X + ga Y); wave-uniform
+    //   (A, 0) p1/p2: c2 1     c4 -17/4  c1 1    c3 -17/4  c5 1    al 1  be 1  ga -1
+    //   (A, 1) p3/p4: c2 1/4   c4 -5/4   c1 1/2  c3 -5/2   c5 2
+    //   (B, 0) p5/p6: c2 4     c4 -5     c1 2    c3 -5/2   c5 1/2
+    //   (B, 1) p0/p7: c0 -1 c2 21/4 c4 -21/4   c1 -1 c3 21/4 c5 -21/4 c7 1    al 0  be 0  ga 1
+    auto store_act = [&](f32x4* buf) __attribute__((always_inline)) {
+        const int sel = pS * 2 + half;                      // wave-uniform
+        // (selected as integers so that they stay in scalar registers: a float ?: chain became a tree of branches)
+        auto pick = [&](unsigned v0, unsigned v1, unsigned v2, unsigned v3) __attribute__((always_inline)) {
+            return __builtin_bit_cast(float, sel == 0 ? v0 : (sel == 1 ? v1 : (sel == 2 ? v2 : v3)));
+        };
+        const float c2 = pick(0x3f800000u, 0x3e800000u, 0x40800000u, 0x40a80000u);        // 1.0 0.25 4.0 5.25
+        const float c4 = pick(0xc0880000u, 0xbfa00000u, 0xc0a00000u, 0xc0a80000u);        // -4.25 -1.25 -5.0 -5.25
+        const float c1 = pick(0x3f800000u, 0x3f000000u, 0x40000000u, 0xbf800000u);        // 1.0 0.5 2.0 -1.0
+        const float c3 = pick(0xc0880000u, 0xc0200000u, 0xc0200000u, 0x40a80000u);        // -4.25 -2.5 -2.5 5.25
+        const float c5 = pick(0x3f800000u, 0x40000000u, 0x3f000000u, 0xc0a80000u);        // 1.0 2.0 0.5 -5.25
+        const bool special = sel == 3;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]), "+v"(xh[5]), "+v"(xh[6]), "+v"(xh[7]));
+        float Ea[6], Eb[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float d[8];
+#pragma unroll
+            for (int r = 1; r < 7; ++r)
+                d[r] = j == 0 ? dpp_shr1(xh[r], xv[r][3]) : (j == 5 ? dpp_shl1(xh[r], xv[r][0]) : xv[r][j - 1]);
+            float X = c2 * d[2] + (c4 * d[4] + d[6]);
+            float Y = c1 * d[1] + (c3 * d[3] + c5 * d[5]);
+            if (special) {                                  // (wave-uniform: pass B, waves 4-7 - the only user of rows 0 and 7)
+                d[0] = j == 0 ? dpp_shr1(xh[0], xv[0][3]) : (j == 5 ? dpp_shl1(xh[0], xv[0][0]) : xv[0][j - 1]);
+                d[7] = j == 0 ? dpp_shr1(xh[7], xv[7][3]) : (j == 5 ? dpp_shl1(xh[7], xv[7][0]) : xv[7][j - 1]);
+                X = X - d[0];
+                Y = Y + d[7];
+                Ea[j] = X;
+                Eb[j] = Y;
+            } else {
+                Ea[j] = X + Y;
+                Eb[j] = X - Y;
+            }
+        }
+        if (HAS_ISC) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                Ea[j] *= xsc;
+                Eb[j] *= xsc;
+            }
+        }
+        float Ua[6], Ub[6];
+        tt(Ea, Ua);
+        tt(Eb, Ub);
+        buf[xlds] = f32x4{Ua[0], Ua[1], Ua[2], Ua[3]};
+        buf[xlds + 1] = f32x4{Ua[4], Ua[5], Ub[0], Ub[1]};
+        buf[xlds + 2] = f32x4{Ub[2], Ub[3], Ub[4], Ub[5]};
+    };
+    auto advance = [&](int& ps, int& ci0) __attribute__((always_inline)) {    // next super-slab, clamped at the last one
+        int nc = ci0 + KS, np = ps;
+        if (nc >= g.CinP) {
+            nc = 0;
+            ++np;
+        }
+        if (np <= 1) {
+            ps = np;
+            ci0 = nc;
+        }
+    };
+
+    // operand addresses (float4 units): A in the wave's ring part, B in X ([ci][unit][6 float4])
+    const int aoff = (lk * 16 + l15) * 3;
+    const int boff = (lk * NU + l15) * 6;
+
+    // ---- prologue: super-slab 0 transformed into X[0], rows of super-slab 1 in flight, ring entries 0-2 loaded
+    int pA = 0, cA = 0;
+    issue_rows(pA, cA, 0, 8);
+    issue_halo(cA);
+    issue_isc(cA);
+    pS = pA;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        Y_DMA(i, 0)
+        Y_DMA(i, 1)
+        Y_DMA(i, 2)
+        w_next();
+    }
+    Y_FENCE
+    halo_permute();
+    store_act(Xb);
+    Y_FENCE
+    advance(pA, cA);
+    issue_rows(pA, cA, 0, 8);
+    issue_halo(cA);
+    issue_isc(cA);
+    pS = pA;
+    Y_FENCE
+    asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)");        // the 9 weight DMAs landed (the 7 youngest loads - super-slab 1 - may stay in flight)
+    __builtin_amdgcn_s_barrier();
+    Y_FENCE
+
+    f32x4 acc[2][12];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 12; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 av[2], bv[2];
+    // group G = 3 hs + pg of a super-slab (hs = half-slot 0..7 = (ci quad hs >> 1, phase half hs & 1), pg = 4 of its 12 phases):
+    //   [DMA chunk pg of half-slot hs + 3 into ring (hs + 3) & 3] [row / halo loads] [counted wait when a new half-slot is first read]
+    //   [reads of group G + 1 into the other operand set] [transform at G = 0] [4 MFMAs of group G]
+    // vmcnt bookkeeping (operations complete in order).  Per super-slab and wave, pass A: G0: D R R R | G1: D R R R | G2: D H |
+    // G3..G23: D (pass B: one more R in G0 and in G1).  Chunk 2 of half-slot hs + 1 was issued as the D of group 3 hs - 4; its first
+    // read is in group 3 hs + 2, after that group's D and loads: younger operations = loads of group 3 hs - 4 + (D + loads) of
+    // groups 3 hs - 3 .. 3 hs + 2 (pass A, the smaller count, is what the waits use):
+    //   hs = 0 (G2): groups 21, 22, 23, 0, 1, 2: 6 D + 3 + 3 + 1 = 13;  hs = 1 (G5): 23, 0, .., 5: 13;  hs = 2 (G8): H of G2 + 6 D = 7;
+    //   hs = 3 .. 7 (G11 .. G23): 6.
+#define Y_READ(c, Xp, hs, pg)                                          \
+    av[c] = Ww[((hs) & 3) * WSL + aoff + (pg)];                        \
+    bv[c] = (Xp)[boff + ((hs) >> 1) * KQ * NU * 6 + ((hs) & 1) * 3 + (pg)];
+#define Y_MFMA(c, hs, pg)                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
+        acc[(hs) & 1][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][i], acc[(hs) & 1][4 * (pg) + i], 0, 0, 0);
+    // one group; GN = group index (compile time), NHS / NPG = half-slot and phase group of group GN + 1
+#define Y_G(GN, WAITN)                                                                                          \
+    Y_DMA((((GN) / 3) + 3) & 3, (GN) % 3)                                                                       \
+    Y_FENCE                                                                                                     \
+    if constexpr ((GN) == 1) {                                                                                  \
+        issue_rows(pA, cA, 4, 8);                                                                               \
+        Y_FENCE                                                                                                 \
+    }                                                                                                           \
+    if constexpr ((GN) == 2) {                                                                                  \
+        issue_halo(cA);                                                                                         \
+        Y_FENCE                                                                                                 \
+    }                                                                                                           \
+    if constexpr ((GN) % 3 == 2) {                                                                              \
+        w_next();                                                                                               \
+        Y_WAITVM(WAITN)                                                                                         \
+    }                                                                                                           \
+    if constexpr ((GN) < 23) {                                                                                  \
+        Y_READ(((GN) + 1) & 1, Xs, ((GN) + 1) / 3, ((GN) + 1) % 3)                                              \
+        Y_FENCE                                                                                                 \
+    }                                                                                                           \
+    if constexpr ((GN) == 0) {                                                                                  \
+        store_act(Xw);                                                                                          \
+        advance(pA, cA);                                                                                        \
+        issue_isc(cA);                                                                                          \
+        pS = pA;                                                                                                \
+        Y_FENCE                                                                                                 \
+        issue_rows(pA, cA, 0, 4);                                                                               \
+        Y_FENCE                                                                                                 \
+    }                                                                                                           \
+    if constexpr ((GN) < 23) {                                                                                  \
+        Y_MFMA((GN) & 1, (GN) / 3, (GN) % 3)                                                                    \
+        Y_FENCE                                                                                                 \
+    }
+
+    Y_READ(0, Xb, 0, 0)
+    halo_permute();                                       // (super-slab 1's halo: waits for its load)
+    int cM = 0, pM = 0;
+    for (int S = 0; S < NS; ++S) {
+        const f32x4* Xs = Xb + (S & 1) * XSZ;
+        f32x4* Xw = Xb + ((S + 1) & 1) * XSZ;
+        Y_G(0, 0) Y_G(1, 0) Y_G(2, 13)
+        Y_G(3, 0) Y_G(4, 0) Y_G(5, 13)
+        Y_G(6, 0) Y_G(7, 0) Y_G(8, 7)
+        Y_G(9, 0) Y_G(10, 0) Y_G(11, 6)
+        Y_G(12, 0) Y_G(13, 0) Y_G(14, 6)
+        Y_G(15, 0) Y_G(16, 0) Y_G(17, 6)
+        Y_G(18, 0) Y_G(19, 0) Y_G(20, 6)
+        Y_G(21, 0) Y_G(22, 0)
+        // G23: D, wait for half-slot 0 of the next super-slab (issued at G17: 6 younger), barrier (X[(S + 1) & 1] complete, nobody
+        // reads X[S & 1] any more: the operands of this group are in registers), first reads of the next super-slab, 4 MFMAs
+        Y_G(23, 6)
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        __builtin_amdgcn_s_barrier();
+        Y_FENCE
+        Y_READ(0, Xw, 0, 0)
+        halo_permute();
+        Y_FENCE
+        Y_MFMA(1, 7, 2)
+        Y_FENCE
+        cM += KS;
+        if (cM >= g.CinP) {
+            cM = 0;
+            if (pM == 0) {
+                // pass boundary: carry the finished phases (p1, p2, p3, p4) into the accumulators of (p5, p6, p0, p7)
+                asm volatile("s_nop 15\n\ts_nop 15");
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float m1 = acc[0][p][e], m2 = acc[0][6 + p][e], m3 = acc[1][p][e], m4 = acc[1][6 + p][e];
+                        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                        acc[0][p][e] = (2.f * s12 + d12) + (8.f * s34 + 2.f * d34);          // 3 m1 + m2 + 10 m3 + 6 m4
+                        acc[0][6 + p][e] = (2.f * s12 - d12) + (8.f * s34 - 2.f * d34);      // m1 + 3 m2 + 6 m3 + 10 m4
+                        acc[1][p][e] = -3.f * s12 - 15.f * s34;
+                        acc[1][6 + p][e] = 0.75f * d12 + 7.5f * d34;
+                    }
+            }
+            ++pM;
+        }
+    }
+#undef Y_G
+#undef Y_MFMA
+#undef Y_READ
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+
+    // ---- output: rows r = 0..3 from (M5, M6, M0, M7) = acc[0][0..5], acc[0][6..11], acc[1][0..5], acc[1][6..11]
+    const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
+    const int t = t0 + 4 * l15;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const int f = fa + row * a.dil;
+        const bool pv = f < a.F && t < a.T;
+        const long sp = pv ? (long)f * a.T + t : 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int co = co0 + wave * 16 + 4 * lk + kk;
+            const float os = has_os ? a.oscale[b * a.Cout + co] : 1.f;
+            const f32x4 rr = (has_res && pv) ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)co * a.res_cs + sp)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            float m[6];
+#pragma unroll
+            for (int tp = 0; tp < 6; ++tp) {
+                const float M5 = acc[0][tp][kk], M6 = acc[0][6 + tp][kk], M0 = acc[1][tp][kk], M7 = acc[1][6 + tp][kk];
+                m[tp] = row == 0 ? (M5 + M6) + M0 : (row == 1 ? 0.5f * (M5 - M6) : (row == 2 ? 0.25f * (M5 + M6) : 0.125f * (M5 - M6) + M7));
+            }
+            const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+            f32x4 y = {m[0] + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + m[5]};
+            const float sc = a.alpha * os;
+            y = y * sc + a.rbeta * rr;
+            if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
+        }
+    }
+#endif
+}
+
+// dst [2 passes][CinP / 4][2 halves][4 ci][CoutP][12]; entry 6 * fl + tp; phase pairs (A,0) = (p1,p2), (A,1) = (p3,p4),
+// (B,0) = (p5,p6), (B,1) = (p0,p7)
+__global__ void pack_wino85_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int tf, int CinP,
+                                   int CoutP, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int co = (int)(i % CoutP);
+    long r = i / CoutP;
+    const int c4 = (int)(r % 4);
+    r /= 4;
+    const int hf = (int)(r % 2);
+    r /= 2;
+    const int cq = (int)(r % (CinP / 4));
+    const int ps = (int)(r / (CinP / 4));
+    const int ci = cq * 4 + c4;
+    double wk[5][3];
+    for (int kh = 0; kh < 5; ++kh)
+        for (int kw = 0; kw < 3; ++kw) wk[kh][kw] = 0;
+    if (!tf) {
+        if (co < Cout && ci < Cin) {
+            const float* p = w + ((long)co * Cin + ci) * 15;
+            for (int kh = 0; kh < 5; ++kh)
+                for (int kw = 0; kw < 3; ++kw) wk[kh][kw] = p[kh * 3 + kw];
+        }
+    } else {
+        if (co < Cin && ci < Cout) {      // packed "Cout" = reference Cin; taps flipped in both axes
+            const float* p = w + ((long)ci * Cin + co) * 15;
+            for (int kh = 0; kh < 5; ++kh)
+                for (int kw = 0; kw < 3; ++kw) wk[kh][kw] = p[(4 - kh) * 3 + (2 - kw)];
+        }
+    }
+    const double G8[8][5] = {{-1, 0, 0, 0, 0},
+                             {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                             {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                             {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                             {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                             {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                             {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                             {0, 0, 0, 0, 1}};
+    const double G3[6][3] = {{0.25, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+    const int fps[2][2][2] = {{{1, 2}, {3, 4}}, {{5, 6}, {0, 7}}};
+    float* d = dst + i * 12;
+    for (int fl = 0; fl < 2; ++fl) {
+        const int fp = fps[ps][hf][fl];
+        double fw[3];
+        for (int kw = 0; kw < 3; ++kw) {
+            double s = 0;
+            for (int kh = 0; kh < 5; ++kh) s += G8[fp][kh] * wk[kh][kw];
+            fw[kw] = s;
+        }
+        for (int tp = 0; tp < 6; ++tp) d[6 * fl + tp] = (float)(G3[tp][0] * fw[0] + G3[tp][1] * fw[1] + G3[tp][2] * fw[2]);
+    }
+}
+
+}  // namespace
+
+extern "C" long babe_conv_packed_size_wino85(int Cout, int Cin, int transpose_flip) {
+    const int co = transpose_flip ? Cin : Cout;
+    const int ci = transpose_flip ? Cout : Cin;
+    return 48L * ((ci + 15) / 16 * 16) * ((co + 127) / 128 * 128);
+}
+
+extern "C" int babe_conv_pack_weights_wino85(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
+                                             void* stream) {
+    BABE_CHECK_ARG(w && dst && Cout > 0 && Cin > 0 && KH == 5 && KW == 3, "conv_pack_weights_wino85: needs a (5,3) kernel");
+    const int co = transpose_flip ? Cin : Cout;
+    const int ci = transpose_flip ? Cout : Cin;
+    const int CinP = (ci + 15) / 16 * 16, CoutP = (co + 127) / 128 * 128;
+    const long total = 4L * CinP * CoutP;
+    hipLaunchKernelGGL(pack_wino85_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, Cin,
+                       transpose_flip, CinP, CoutP, total);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+/* 1 if the experimental F(4,5) x F(4,3) kernel can run this problem: 128-channel output tiles, 16-channel input slabs, T a multiple
+ * of 4 and at least 64, one source, 16-byte aligned views */
+extern "C" int babe_conv2d_wino85_supported(const babe_conv_args* ap) {
+    if (!ap) return 0;
+    const babe_conv_args& a = *ap;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (a.KH != 5 || a.KW != 3 || a.T % 4 != 0 || a.T < 64 || a.dil < 1) return 0;
+    if (a.Cin < 16 || a.Cin % 16 != 0 || a.Cout % 128 != 0) return 0;
+    if (!al16(a.in) || a.in_bs % 4 || a.in_cs % 4 || a.in2) return 0;
+    if (!al16(a.out) || a.out_bs % 4 || a.out_cs % 4) return 0;
+    if (a.res && (!al16(a.res) || a.res_bs % 4 || a.res_cs % 4)) return 0;
+    const long lim = 0x3fffffffL / 4;
+    if ((long)a.Cin * a.in_cs >= lim || (long)a.F * a.T >= lim) return 0;
+    if (48L * a.Cin * a.Cout * 4 >= 0x7fffffffL) return 0;
+    return 1;
+}
+
+/* fraction of the row-quad x time slots of a launch that hold real outputs */
+static double wino85_fill(const babe_conv_args& a) {
+    const long n = (a.F + a.dil - 1) / a.dil, nq = (n + 3) / 4;
+    return ((double)a.F / (4.0 * nq * a.dil)) * ((double)a.T / (64.0 * ((a.T + 63) / 64)));
+}
+
+extern "C" int babe_conv2d_wino85_preferred(const babe_conv_args* ap) {
+    if (!babe_conv2d_wino85_supported(ap)) return 0;
+    return wino85_fill(*ap) >= 0.85 ? 1 : 0;
+}
+
+extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino85, void* stream) {
+    BABE_CHECK_ARG(ap && w_wino85, "conv2d_wino85: null args");
+    BABE_CHECK_ARG(babe_conv2d_wino85_supported(ap), "conv2d_wino85: unsupported problem");
+    const babe_conv_args& a = *ap;
+    Wino85Geom g;
+    g.CinP = a.Cin;
+    g.CoutP = a.Cout;
+    g.tiles_t = cdiv(a.T, 64);
+    g.nquads = cdiv(cdiv(a.F, a.dil), 4);
+    const double flops = babe_conv_flops(a);         // 48 multiplies per 16 outputs instead of 240: 0.2 of the direct count
+    BabeProfScope prof(BABE_SLOT_CONV53_WINO45, babe_conv_bytes(a), flops, flops * 0.2, stream);
+    const size_t lds = (size_t)(2 * 16 * 16 * 6 + 4 * 8 * 4 * 16 * 3) * 16;   // 144 KB
+    static std::atomic<unsigned long long> attr{0};
+    if (babe_lds_optin(attr, {reinterpret_cast<const void*>(&conv_wino85_kernel<true>),
+                              reinterpret_cast<const void*>(&conv_wino85_kernel<false>)}, (int)lds) != hipSuccess) {
+        babe_set_error("conv2d_wino85: cannot opt in to %zu bytes of LDS", lds);
+        return BABE_ERR_HIP;
+    }
+    dim3 grid(g.tiles_t * a.dil * g.nquads, a.Cout / 128, a.B);
+    if (a.in_scale) hipLaunchKernelGGL((conv_wino85_kernel<true>), grid, dim3(512), lds, (hipStream_t)stream, a, g, w_wino85);
+    else hipLaunchKernelGGL((conv_wino85_kernel<false>), grid, dim3(512), lds, (hipStream_t)stream, a, g, w_wino85);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}

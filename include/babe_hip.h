@@ -170,6 +170,15 @@ int babe_resample_res(const float* in, long in_bs, long in_cs, const float* res,
 int babe_resample_sinc(const float* x, long x_bs, float* out, long out_bs, int B, long L_in, long L_out, const float* kernel,
                        const int* krange, int orig, int new_, int width, void* stream);
 
+/* ---- EXPERIMENTAL (round 5, not on the product path unless BABE_CONV_F45=1): nested Winograd F(4,5) x F(4,3) for the same (5,3)
+ * convs as babe_conv2d_wino45 - 3.0 multiplies per output instead of 4.5 (csrc/conv_wino85.hip).  128-channel output tiles,
+ * Cin % 16 == 0; weights [2 passes][Cin/4][2][4][Cout][12] from babe_conv_pack_weights_wino85. */
+long babe_conv_packed_size_wino85(int Cout, int Cin, int transpose_flip);
+int babe_conv_pack_weights_wino85(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip, void* stream);
+int babe_conv2d_wino85_supported(const babe_conv_args* a);
+int babe_conv2d_wino85_preferred(const babe_conv_args* a);
+int babe_conv2d_wino85(const babe_conv_args* a, const float* w_wino85, void* stream);
+
 /* ---- the whole UNet body from one call: networks/cqtdiff+.py:746-839 (forward), ResnetBlock :452-493, and its input-VJP
  * (the autograd pass of testing/blind_bwe_sampler.py:120).  csrc/unet_engine.hip sequences the op-level functions of this header
  * exactly as babe_amd/networks/unet_engine.py does (bit-identical results); fp32 convs.  All device memory is the caller's. */

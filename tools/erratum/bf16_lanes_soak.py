@@ -3,7 +3,7 @@ was built without the SLP vectoriser): the benchmark-width network, four clips =
 bit-identical and every clip within the bf16 bar of the fp32 reference golden."""
 import os, sys, torch
 os.environ.setdefault("BABE_BF16_LANES", "1")          # the opt-in this soak is about
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import test_gpu_unet_full as tf
 s = tf.load("sampler_full_46046.npz")
