@@ -30,6 +30,7 @@ namespace {
 
 struct Wino85Geom {
     int CinP, CoutP, tiles_t, nquads;      // nquads: row quads per residue class
+    int xcd, per_xcd, total, ncb;          // XCD-contiguous tile order: tiles per XCD, tiles per batch item, channel blocks
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -52,9 +53,20 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lk = lane >> 4;
     const int b = blockIdx.z;
-    const int co0 = blockIdx.y * BN;
-    const int tile_t = blockIdx.x % g.tiles_t;
-    const int Q = blockIdx.x / g.tiles_t;
+    // XCD-aware tile order: workgroups go to the 8 XCDs round-robin by linear id, each XCD has its own L2.  The tiles that read the
+    // same input rows - the channel blocks of a tile, then the neighbouring row quads of a residue class (4 of their 8 rows are
+    // shared) - are handed to ONE XCD as a contiguous chunk of the list [time tile][class][quad][channel block].
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (g.xcd) {
+        const int lin = (bx & 7) * g.per_xcd + (bx >> 3);
+        if ((bx >> 3) >= g.per_xcd || lin >= g.total) return;
+        by = lin % g.ncb;
+        bx = lin / g.ncb;
+    }
+    const int co0 = by * BN;
+    const int nQ = a.dil * g.nquads;
+    const int tile_t = g.xcd ? bx / nQ : bx % g.tiles_t;
+    const int Q = g.xcd ? bx % nQ : bx / g.tiles_t;
     const int t0 = tile_t * 64;
     const int cls = Q / g.nquads;
     const int fa = Q < a.dil * g.nquads ? cls + 4 * (Q - cls * g.nquads) * a.dil : a.F + 8 * a.dil;   // first output row
@@ -76,6 +88,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
         const int fr = fa + (r - 2) * a.dil;
         const bool ok = fr >= 0 && fr < a.F && s_t < a.T;
         er[r] = ok ? (unsigned)((fr * a.T + s_t) * 4) + chb : OOBH;
+        if (W85_ABL & 128) er[r] = (unsigned)((r * 64 + 4 * s_tu) * 4) + chb;       // (always the same 8 KB: L1 hits)
     }
     unsigned ehalo = OOBH;
     {
@@ -102,7 +115,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
         sW = sW < sWend ? sW : sWend;
     };
     f32x4* const Ww = Wb + wave * WWV;
+#ifndef W85_ABL
+#define W85_ABL 0      // timing ablations only (tools/f45_ablate.py): 1 no transform arithmetic, 2 no row loads, 4 no weight DMA,
+#endif                 // 8 no operand reads, 16 no MFMA, 32 rows loaded by waves 0-3 only, 64 / 128 row loads that always hit L2 / L1 - results are wrong
+#if W85_ABL & 4
+#define Y_DMA(rp, j)
+#else
 #define Y_DMA(rp, j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(Ww + (rp) * WSL + (j) * 64), 16, wvl[j], sW, 0, 0);
+#endif
 #define Y_FENCE __builtin_amdgcn_sched_barrier(0);
 #ifdef W85_SAFE
 #define Y_WAITVM(n) asm volatile("s_waitcnt vmcnt(0)");
@@ -119,7 +139,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     // +-1, +-2 do not touch them).  The counted waits below assume the SIX-row form - with the two extra loads of pass B they just
     // wait for two older operations more, which landed long ago.
     auto issue_rows = [&](int ps, int ci0, int r0, int r1) __attribute__((always_inline)) {
-        const int so = (ci0 + 4 * wq4) * cs1 * 4;
+        const int so = (W85_ABL & (64 | 128)) ? 0 : (ci0 + 4 * wq4) * cs1 * 4;       // (64: always the first 4 channels: L2 hits)
+        if ((W85_ABL & 2) || ((W85_ABL & 32) && half)) return;
 #pragma unroll
         for (int r = 1; r < 7; ++r) {
             if (r < r0 || r >= r1) continue;
@@ -132,6 +153,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     };
     auto issue_halo = [&](int ci0) __attribute__((always_inline)) {
         const int so = (ci0 + 4 * wq4) * cs1 * 4;
+        if ((W85_ABL & 2) || ((W85_ABL & 32) && half)) return;
         xhl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ehalo, so, 0));
     };
     auto issue_isc = [&](int ci0) __attribute__((always_inline)) {
@@ -166,6 +188,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     //   (B, 0) p5/p6: c2 4     c4 -5     c1 2    c3 -5/2   c5 1/2
     //   (B, 1) p0/p7: c0 -1 c2 21/4 c4 -21/4   c1 -1 c3 21/4 c5 -21/4 c7 1    al 0  be 0  ga 1
     auto store_act = [&](f32x4* buf) __attribute__((always_inline)) {
+        if (W85_ABL & 1) {
+            buf[xlds] = xv[1] + xv[0];
+            buf[xlds + 1] = xv[2] + xv[7];
+            buf[xlds + 2] = xv[3] + f32x4{xh[1], xh[2], xh[0], xh[7]};
+            return;
+        }
         const int sel = pS * 2 + half;                      // wave-uniform
         // (selected as integers so that they stay in scalar registers: a float ?: chain became a tree of branches)
         auto pick = [&](unsigned v0, unsigned v1, unsigned v2, unsigned v3) __attribute__((always_inline)) {
@@ -262,6 +290,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
 #pragma unroll
         for (int p = 0; p < 12; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 av[2], bv[2];
+    if (W85_ABL & 8) av[0] = av[1] = bv[0] = bv[1] = f32x4{1.f, 2.f, 3.f, 4.f};
     // group G = 3 hs + pg of a super-slab (hs = half-slot 0..7 = (ci quad hs >> 1, phase half hs & 1), pg = 4 of its 12 phases):
     //   [DMA chunk pg of half-slot hs + 3 into ring (hs + 3) & 3] [row / halo loads] [counted wait when a new half-slot is first read]
     //   [reads of group G + 1 into the other operand set] [transform at G = 0] [4 MFMAs of group G]
@@ -271,10 +300,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     // groups 3 hs - 3 .. 3 hs + 2 (pass A, the smaller count, is what the waits use):
     //   hs = 0 (G2): groups 21, 22, 23, 0, 1, 2: 6 D + 3 + 3 + 1 = 13;  hs = 1 (G5): 23, 0, .., 5: 13;  hs = 2 (G8): H of G2 + 6 D = 7;
     //   hs = 3 .. 7 (G11 .. G23): 6.
+#if W85_ABL & 8
+#define Y_READ(c, Xp, hs, pg) asm volatile("" : "+v"(av[c]), "+v"(bv[c]));
+#else
 #define Y_READ(c, Xp, hs, pg)                                          \
     av[c] = Ww[((hs) & 3) * WSL + aoff + (pg)];                        \
     bv[c] = (Xp)[boff + ((hs) >> 1) * KQ * NU * 6 + ((hs) & 1) * 3 + (pg)];
+#endif
 #define Y_MFMA(c, hs, pg)                                              \
+    if (!(W85_ABL & 16))                                               \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
         acc[(hs) & 1][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][i], acc[(hs) & 1][4 * (pg) + i], 0, 0, 0);
     // one group; GN = group index (compile time), NHS / NPG = half-slot and phase group of group GN + 1
@@ -506,7 +540,7 @@ extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino8
     g.tiles_t = cdiv(a.T, 64);
     g.nquads = cdiv(cdiv(a.F, a.dil), 4);
     const double flops = babe_conv_flops(a);         // 48 multiplies per 16 outputs instead of 240: 0.2 of the direct count
-    BabeProfScope prof(BABE_SLOT_CONV53_WINO45, babe_conv_bytes(a), flops, flops * 0.2, stream);
+    BabeProfScope prof(BABE_SLOT_CONV53_WINO85, babe_conv_bytes(a), flops, flops * 0.2, stream);
     const size_t lds = (size_t)(2 * 16 * 16 * 6 + 4 * 8 * 4 * 16 * 3) * 16;   // 144 KB
     static std::atomic<unsigned long long> attr{0};
     if (babe_lds_optin(attr, {reinterpret_cast<const void*>(&conv_wino85_kernel<true>),
@@ -514,7 +548,13 @@ extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino8
         babe_set_error("conv2d_wino85: cannot opt in to %zu bytes of LDS", lds);
         return BABE_ERR_HIP;
     }
+    static const int xcd_order = [] { const char* e = getenv("BABE_W85_XCD"); return e ? atoi(e) : 1; }();
+    g.xcd = xcd_order;
+    g.ncb = a.Cout / 128;
+    g.total = g.tiles_t * a.dil * g.nquads * g.ncb;
+    g.per_xcd = (g.total + 7) / 8;
     dim3 grid(g.tiles_t * a.dil * g.nquads, a.Cout / 128, a.B);
+    if (g.xcd) grid = dim3(8 * g.per_xcd, 1, a.B);
     if (a.in_scale) hipLaunchKernelGGL((conv_wino85_kernel<true>), grid, dim3(512), lds, (hipStream_t)stream, a, g, w_wino85);
     else hipLaunchKernelGGL((conv_wino85_kernel<false>), grid, dim3(512), lds, (hipStream_t)stream, a, g, w_wino85);
     BABE_LAUNCH_CHECK();

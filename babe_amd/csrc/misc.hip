@@ -32,7 +32,7 @@ const char* const kSlotNames[BABE_NSLOTS] = {
     "conv53_wino4", "conv53_wino2", "conv53_direct", "conv11", "conv_bf16", "dft_stage", "gn_stats", "scale_gelu",
     "gn_bwd_partial", "gn_bwd_apply", "resample", "axpby", "film", "cqt_band_analysis", "cqt_band_synthesis",
     "cqt_gather", "stft_fwd", "istft", "mag_stats", "filter_fit", "sampler", "denoiser", "conv53_fewco",
-    "conv_bf16p", "conv53_wino45"};
+    "conv_bf16p", "conv53_wino45", "conv53_wino85"};
 }  // namespace
 
 extern "C" void babe_prof_begin(int slot, double bytes, double flops, double exec_flops, void* stream) {

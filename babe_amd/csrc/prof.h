@@ -31,6 +31,7 @@ enum BabeProfSlot {
     BABE_SLOT_CONV53_FEWCO,       // (5,3) conv with <= 4 output channels on the vector ALU (conv_fewco.hip)
     BABE_SLOT_CONV_BF16P,         // pipelined bf16 (5,3) conv (conv_bf16p.hip)
     BABE_SLOT_CONV53_WINO45,      // (5,3) conv, nested Winograd F(2,5) x F(4,3) (conv_wino45.hip)
+    BABE_SLOT_CONV53_WINO85,      // (5,3) conv, nested Winograd F(4,5) x F(4,3) (conv_wino85.hip)
     BABE_NSLOTS
 };
 

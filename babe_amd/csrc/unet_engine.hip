@@ -35,6 +35,8 @@ extern "C" int babe_conv2d_auto(babe_conv_args* a, const babe_packed_conv* pc, i
     a->w_packed = (const float*)wq;
     const float* w45 = transpose ? pc->bwd_wino45 : pc->fwd_wino45;
     if (pc->w_raw && a->Cout <= 4 && babe_conv2d_fewco_supported(a)) return babe_conv2d_fewco(a, pc->w_raw, transpose, stream);
+    const float* w85 = transpose ? pc->bwd_wino85 : pc->fwd_wino85;
+    if (w85 && !a->in2 && babe_conv2d_wino85_preferred(a)) return babe_conv2d_wino85(a, w85, stream);
     if (w45 && babe_conv2d_wino45_preferred(a)) return babe_conv2d_wino45(a, w45, stream);
     if (pc->fwd_wino4 && babe_conv2d_wino4_supported(a)) return babe_conv2d_wino4(a, transpose ? pc->bwd_wino4 : pc->fwd_wino4, stream);
     if (pc->fwd_wino && babe_conv2d_wino_supported(a)) return babe_conv2d_wino(a, transpose ? pc->bwd_wino : pc->fwd_wino, stream);

@@ -15,7 +15,7 @@ _I, _P = C.c_int, C.c_void_p
 class CPackedConv(C.Structure):
     _fields_ = [("Cout", _I), ("Cin", _I), ("KH", _I), ("KW", _I), ("nt", _I), ("splits", _I), ("fwd", _P), ("bwd", _P),
                 ("fwd_wino", _P), ("bwd_wino", _P), ("fwd_wino4", _P), ("bwd_wino4", _P), ("fwd_wino45", _P), ("bwd_wino45", _P),
-                ("w_raw", _P)]
+                ("w_raw", _P), ("fwd_wino85", _P), ("bwd_wino85", _P)]
 
 
 class CBlock(C.Structure):
@@ -61,7 +61,7 @@ def _pc(dst, pc):
     g = lambda k: ptr(getattr(pc, k, None)) if getattr(pc, k, None) is not None else None
     dst.Cout, dst.Cin, dst.KH, dst.KW, dst.nt, dst.splits = pc.Cout, pc.Cin, pc.KH, pc.KW, pc.nt, pc.splits
     dst.fwd, dst.bwd = g("fwd"), g("bwd")
-    for k in ("fwd_wino", "bwd_wino", "fwd_wino4", "bwd_wino4", "fwd_wino45", "bwd_wino45", "w_raw"):
+    for k in ("fwd_wino", "bwd_wino", "fwd_wino4", "bwd_wino4", "fwd_wino45", "bwd_wino45", "w_raw", "fwd_wino85", "bwd_wino85"):
         setattr(dst, k, g(k))
 
 

@@ -28,8 +28,9 @@ WINOGRAD = _W != "0"
 WINOGRAD4 = _W not in ("0", "2", "1")
 # nested Winograd F(2,5) x F(4,3) (csrc/conv_wino45.hip) for the (5,3) layers it supports; BABE_CONV_WINO45=0 switches it off
 WINOGRAD45 = WINOGRAD4 and os.environ.get("BABE_CONV_WINO45", "1") != "0"
-# EXPERIMENTAL nested Winograd F(4,5) x F(4,3) (csrc/conv_wino85.hip, round 5): opt-in, fp32, 128-channel output tiles
-WINOGRAD85 = WINOGRAD45 and os.environ.get("BABE_CONV_F45", "0") == "1"
+# nested Winograd F(4,5) x F(4,3) (csrc/conv_wino85.hip) for the (5,3) layers with 128-channel output tiles whose row quads are
+# at least 85 % full (babe_conv2d_wino85_preferred); BABE_CONV_F45=0 leaves them to the F(2,5) x F(4,3) kernel
+WINOGRAD85 = WINOGRAD45 and os.environ.get("BABE_CONV_F45", "1") != "0"
 
 
 class PackedConv:
@@ -116,7 +117,8 @@ class PackedConv:
 def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=None, oscale=None, alpha=1.0, rbeta=0.0,
            force_nested=False, force_f45=False):
     """out = alpha*conv(x[,x2]; W)*oscale + rbeta*res   (transpose=True: input-VJP weights).
-    force_nested: take the nested-Winograd kernel whenever it CAN run the problem (tests), not only when it is preferred."""
+    force_nested: take the nested-Winograd F(2,5) x F(4,3) kernel whenever it CAN run the problem (tests), not only when it is
+    preferred; force_f45: the same for the F(4,5) x F(4,3) kernel."""
     a = ConvArgs()
     B, C1, F, T = x.shape
     Cin = pc.Cout if transpose else pc.Cin
@@ -151,7 +153,7 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
         check(lib().babe_conv2d_bf16(C.byref(a), ptr(wq), pc.splits, stream()), "conv2d_bf16")
     elif FEWCO and getattr(pc, "w_raw", None) is not None and Cout <= 4 and lib().babe_conv2d_fewco_supported(C.byref(a)):
         check(lib().babe_conv2d_fewco(C.byref(a), ptr(pc.w_raw), int(transpose), stream()), "conv2d_fewco")
-    elif getattr(pc, "bwd_wino85" if transpose else "fwd_wino85", None) is not None and x2 is None and (
+    elif getattr(pc, "bwd_wino85" if transpose else "fwd_wino85", None) is not None and x2 is None and not force_nested and (
             lib().babe_conv2d_wino85_supported(C.byref(a)) if force_f45 else lib().babe_conv2d_wino85_preferred(C.byref(a))):
         check(lib().babe_conv2d_wino85(C.byref(a), ptr(pc.bwd_wino85 if transpose else pc.fwd_wino85), stream()), "conv2d_wino85")
     elif getattr(pc, "bwd_wino45" if transpose else "fwd_wino45", None) is not None and (lib().babe_conv2d_wino45_supported(C.byref(a)) if force_nested

@@ -187,6 +187,7 @@ typedef struct {                       /* every image babe_amd/ops.py::PackedCon
     const void *fwd, *bwd;             /* babe_conv_pack_weights_nt (fp32) or babe_conv_pack_weights_bf16 images, transpose_flip 0 / 1 */
     const float *fwd_wino, *bwd_wino, *fwd_wino4, *bwd_wino4, *fwd_wino45, *bwd_wino45;
     const float* w_raw;                /* reference layout, for babe_conv2d_fewco (<= 4 channels on one side) */
+    const float *fwd_wino85, *bwd_wino85;  /* babe_conv_pack_weights_wino85 images (128-channel output tiles), or NULL */
 } babe_packed_conv;
 /* conv with the kernel chosen by the library; a->w_packed, Cin, Cout, KH, KW are filled in from pc / transpose */
 int babe_conv2d_auto(babe_conv_args* a, const babe_packed_conv* pc, int transpose, void* stream);

@@ -30,15 +30,16 @@ def test_unet_plan_structs_have_the_headers_layout(tmp_path):
         pytest.skip("no C compiler")
     from babe_amd.networks import unet_c as uc
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
                    ' sizeof(babe_packed_conv), sizeof(babe_unet_block), sizeof(babe_unet_plan_desc), offsetof(babe_packed_conv, w_raw),'
+                   ' offsetof(babe_packed_conv, bwd_wino85),'
                    ' offsetof(babe_unet_block, gamma), offsetof(babe_unet_block, film_gate), offsetof(babe_unet_plan_desc, pyr_conv));return 0;}\n'
                    % os.path.join(ROOT, "include", "babe_hip.h"))
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
     want = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     got = [ctypes.sizeof(uc.CPackedConv), ctypes.sizeof(uc.CBlock), ctypes.sizeof(uc.CPlanDesc), uc.CPackedConv.w_raw.offset,
-           uc.CBlock.gamma.offset, uc.CBlock.film_gate.offset, uc.CPlanDesc.pyr_conv.offset]
+           uc.CPackedConv.bwd_wino85.offset, uc.CBlock.gamma.offset, uc.CBlock.film_gate.offset, uc.CPlanDesc.pyr_conv.offset]
     assert got == want, (got, want)
 
 

@@ -668,3 +668,84 @@ def test_conv2d_nested_winograd_vs_float64(ops, B, C1, C2, Cout, Fq, T, dil):
     e2 = rel(gx, gref)
     print(f"nested Winograd Cin={Cin} Cout={Cout} F={Fq} T={T} dil={dil}: fwd {e0:.2e}, epilogue {e1:.2e}, vjp {e2:.2e} (wino45 launches {n45})")
     assert e0 < 1e-5 and e1 < 1e-5 and e2 < 1e-5
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Fq,T,dil", [
+    (1, 128, 128, 48, 128, 2),         # whole tiles
+    (1, 256, 256, 28, 64, 4),          # 7 rows per class: the second row quad has one empty row; two channel blocks
+    (2, 128, 256, 40, 100, 1),         # ragged T (100 = 64 + 36), B = 2
+    (1, 96, 128, 56, 64, 8),           # 96 input channels = 6 super-slabs per pass; the VJP (96 output channels) is not this kernel's
+    (1, 128, 128, 24, 192, 16),        # dilation above the rows per class: classes of 1 and 2 rows
+    (1, 256, 128, 448, 64, 64),        # the benchmark's deepest geometry
+    (1, 16, 128, 9, 64, 1),            # ONE 16-channel super-slab per pass; 9 rows = 3 quads, the last with one row
+    (3, 144, 384, 21, 132, 3),         # three channel blocks, odd dilation, T % 64 = 4, B = 3
+])
+def test_conv2d_nested_winograd_f45_vs_float64(ops, B, Cin, Cout, Fq, T, dil):
+    """csrc/conv_wino85.hip - F(4,5) along frequency x F(4,3) along time, two accumulator-carried passes of four frequency phases -
+    against the float64 direct convolution: forward with the fused epilogue and the input-VJP form with a per-channel input scale.
+    Bound 1e-5 relative, the bar of the F(2,5) x F(4,3) kernel (measured 3.5-5.5e-6: the 8-point set 0, +-1, +-2, +-1/2, inf rounds
+    ~1.6x worse than the 6-point one, profiles/r05_wino_f45_estimate.txt)."""
+    from babe_amd._lib import dispatch_counts
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + T + dil)
+    x = torch.randn(B, Cin, Fq, T, generator=g)
+    w = torch.randn(Cout, Cin, 5, 3, generator=g) / math.sqrt(Cin * 15)
+    ref = UN.conv_same(x.double(), w.double(), dil)
+    pc = ops.PackedConv(w.cuda())
+    assert pc.fwd_wino85 is not None
+    out = torch.empty(B, Cout, Fq, T, device="cuda")
+    dispatch_counts(reset=True)
+    ops.conv2d(x.cuda(), pc, out, dil=dil, force_f45=True)
+    assert dispatch_counts()["conv53_wino85"] == 1
+    e0 = rel(out, ref)
+    res = torch.randn(B, Cout, Fq, T, generator=g)
+    osc = torch.randn(B, Cout, generator=g)
+    out2 = res.cuda().clone()
+    ops.conv2d(x.cuda(), pc, out2, dil=dil, res=out2, oscale=osc.cuda(), alpha=0.7, rbeta=0.3, force_f45=True)
+    e1 = rel(out2, 0.7 * ref * osc[:, :, None, None].double() + 0.3 * res.double())
+    gy = torch.randn(B, Cout, Fq, T, generator=g)
+    isc = torch.randn(B, Cout, generator=g)
+    xr = x.double().requires_grad_(True)
+    y = UN.conv_same(xr, w.double(), dil)
+    gref, = torch.autograd.grad((y * (gy * isc[:, :, None, None]).double()).sum(), xr)
+    gx = torch.empty(B, Cin, Fq, T, device="cuda")
+    dispatch_counts(reset=True)
+    ops.conv2d(gy.cuda(), pc, gx, dil=dil, transpose=True, in_scale=isc.cuda(), force_f45=True)
+    n85 = dispatch_counts()["conv53_wino85"]
+    assert n85 == (1 if Cin % 128 == 0 else 0)           # (the transposed conv has Cin output channels)
+    e2 = rel(gx, gref)
+    print(f"F(4,5) x F(4,3) Cin={Cin} Cout={Cout} F={Fq} T={T} dil={dil}: fwd {e0:.2e}, epilogue {e1:.2e}, vjp {e2:.2e} (wino85 launches {n85})")
+    assert e0 < 1e-5 and e1 < 1e-5 and e2 < 1e-5
+
+
+def test_conv2d_f45_dispatch_rule_and_tile_order(ops):
+    """Which launches take the F(4,5) x F(4,3) kernel by default: 128-channel output tiles whose row quads x time tiles are >= 85 %
+    full (babe_conv2d_wino85_preferred); force_nested keeps the F(2,5) x F(4,3) kernel; two-source convs never take it.  The
+    XCD-contiguous tile order only renumbers the workgroups: results are bit-identical for every batch item."""
+    from babe_amd._lib import dispatch_counts
+    g = torch.Generator().manual_seed(85)
+    w = (torch.randn(128, 128, 5, 3, generator=g) / math.sqrt(128 * 15)).cuda()
+    pc = ops.PackedConv(w)
+    for Fq, T, dil, want in ((64, 128, 4, 1), (40, 64, 8, 0), (48, 64, 8, 0), (56, 64, 2, 1), (64, 68, 1, 0)):
+        # rows per class / quads: 16/4 full; 5 -> 2 quads = 0.625; 6 -> 2 quads = 0.75; 28 -> 7 quads full; T 68 of 128 = 0.53
+        x = torch.randn(2, 128, Fq, T, generator=g).cuda()
+        out = torch.empty(2, 128, Fq, T, device="cuda")
+        dispatch_counts(reset=True)
+        ops.conv2d(x, pc, out, dil=dil)
+        c = dispatch_counts()
+        assert c["conv53_wino85"] == want and c["conv53_wino85"] + c["conv53_wino45"] + c["conv53_wino4"] == 1, (Fq, T, dil, c)
+        dispatch_counts(reset=True)
+        out45 = torch.empty_like(out)
+        ops.conv2d(x, pc, out45, dil=dil, force_nested=True)
+        assert dispatch_counts()["conv53_wino45"] == 1
+        assert rel(out, out45) < 1e-5
+        x1 = torch.empty(1, 128, Fq, T, device="cuda").copy_(x[1:])
+        o1 = torch.empty(1, 128, Fq, T, device="cuda")
+        ops.conv2d(x1, pc, o1, dil=dil, force_f45=True)
+        o2 = torch.empty_like(out)
+        ops.conv2d(x, pc, o2, dil=dil, force_f45=True)
+        assert torch.equal(o2[1:], o1)                                    # batch items are independent launches of the same tiles
+    xa, xb = torch.randn(1, 64, 64, 128, generator=g).cuda(), torch.randn(1, 64, 64, 128, generator=g).cuda()
+    out = torch.empty(1, 128, 64, 128, device="cuda")
+    dispatch_counts(reset=True)
+    ops.conv2d(xa, pc, out, dil=4, x2=xb)
+    assert dispatch_counts()["conv53_wino85"] == 0

@@ -69,7 +69,7 @@ def test_full_width_L46046_vs_reference_golden():
     assert ey < TOL_FWD and eg < TOL_VJP
     # frame counts 512 ... 8: the T=8 layers (enc6, the two pyramid convs that run at 8 frames, mid, dec6 = 23 convs) are
     # below F(4,3)'s 16-frame minimum and run the direct kernel; everything else must be on the F(4,3) kernel
-    assert cf["conv53_wino4"] + cf["conv53_wino45"] + cf["conv53_direct"] == 82 and cf["conv53_direct"] <= 23 and cf["conv53_wino2"] == 0, cf
+    assert cf["conv53_wino4"] + cf["conv53_wino45"] + cf["conv53_wino85"] + cf["conv53_direct"] == 82 and cf["conv53_direct"] <= 23 and cf["conv53_wino2"] == 0, cf
     assert cf["conv_bf16"] == 0 and cb["conv_bf16"] == 0
 
 
@@ -84,11 +84,13 @@ def test_full_width_L368368_vs_reference_golden_all_wino4():
     # forward: 75 dilated ResnetBlock convs + 7 pyramid projections, all on the Winograd kernels: the nested
     # F(2,5) x F(4,3) kernel where its tiles are full (64 / 128 / 256 channels), conv_wino4p elsewhere (96 channels, the
     # 2-channel pyramid inputs, the high dilations of the 320- and 384-bin levels)
-    assert cf["conv53_wino4"] + cf["conv53_wino45"] == 82 and cf["conv53_wino45"] >= 40, cf
+    # (round 5: the 128- and 256-channel layers whose row quads are at least 85 % full take the F(4,5) x F(4,3) kernel)
+    assert cf["conv53_wino4"] + cf["conv53_wino45"] + cf["conv53_wino85"] == 82 and cf["conv53_wino45"] + cf["conv53_wino85"] >= 40, cf
+    assert cf["conv53_wino85"] >= 25 and cb["conv53_wino85"] >= 25, (cf, cb)
     assert cf["conv53_wino2"] == 0 and cf["conv53_direct"] == 0, cf
     # VJP: the 75 dilated convs on F(4,3); the 7 pyramid projections transposed have 2 output channels and run on the
     # vector-ALU kernel (csrc/conv_fewco.hip)
-    assert cb["conv53_wino4"] + cb["conv53_wino45"] == 75 and cb["conv53_wino45"] >= 40, cb
+    assert cb["conv53_wino4"] + cb["conv53_wino45"] + cb["conv53_wino85"] == 75 and cb["conv53_wino45"] + cb["conv53_wino85"] >= 40, cb
     assert cb["conv53_fewco"] == 7 and cb["conv53_wino2"] == 0 and cb["conv53_direct"] == 0, cb
     assert cf["conv_bf16"] == 0 and cb["conv_bf16"] == 0
 
@@ -111,7 +113,8 @@ def test_full_width_two_lanes_equal_single_stream_bit_exact():
     assert torch.equal(y2, y1) and torch.equal(g2, g1)
     assert torch.equal(y1[0], y1[1]) and torch.equal(g1[0], g1[1])
     assert rel(y1[:1], g["y"]) < TOL_FWD and rel(g1[:1], g["gx"]) < TOL_VJP
-    assert cf["conv53_wino4"] + cf["conv53_wino45"] == 82 and cb["conv53_wino4"] + cb["conv53_wino45"] == 75
+    assert cf["conv53_wino4"] + cf["conv53_wino45"] + cf["conv53_wino85"] == 82
+    assert cb["conv53_wino4"] + cb["conv53_wino45"] + cb["conv53_wino85"] == 75
 
 
 # ---- reduced-precision builds at FULL width.  The reference is fp32-only; 'bf16x3' (hi/lo split, three
@@ -219,7 +222,7 @@ def test_full_width_blind_sampler_two_lanes_vs_reference_golden():
     # T = 3, order 2: 5 score evaluations per lane = 5 forwards + 5 VJPs per lane; frames 512..8, so the layers with >= 16
     # frames are on the F(4,3) kernel and only the 8-frame ones on the direct kernel
     print("full-width sampler dispatch:", {k: v for k, v in cnt.items() if v})
-    assert cnt["conv53_wino4"] + cnt["conv53_wino45"] >= 2 * 5 * (59 + 52) and cnt["conv53_wino2"] == 0 and cnt["conv_bf16"] == 0, cnt
+    assert cnt["conv53_wino4"] + cnt["conv53_wino45"] + cnt["conv53_wino85"] >= 2 * 5 * (59 + 52) and cnt["conv53_wino2"] == 0 and cnt["conv_bf16"] == 0, cnt
     assert cnt["conv53_direct"] <= 2 * 5 * (23 + 23), cnt
 
 
