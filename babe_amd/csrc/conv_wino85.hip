@@ -1,4 +1,4 @@
-// EXPERIMENTAL (round 5, opt-in: BABE_CONV_F45=1): nested Winograd F(4,5) along FREQUENCY x F(4,3) along TIME for the
+// Nested Winograd F(4,5) along FREQUENCY x F(4,3) along TIME for the
 // frequency-dilated (5,3) Conv2d (networks/cqtdiff+.py:79-88, 433-436), fp32 MFMA.  A unit = 4 output rows of one residue class
 // (f, f + d, f + 2d, f + 3d) x 4 time steps from an 8-row x 6-sample patch: 8 x 6 = 48 products per (ci, co) per 16 outputs =
 // 3.0 per output (conv_wino45.hip: 4.5).  Interpolation points 0, +-1, +-2, +-1/2, inf along frequency (the classic 8-point set),
@@ -14,9 +14,12 @@
 // M'_B = C_B^-1 C_A M_A:   p5' = 3 m1 + m2 + 10 m3 + 6 m4,  p6' = m1 + 3 m2 + 6 m3 + 10 m4,  p0' = -3 (m1 + m2) - 15 (m3 + m4),
 //                          p7' = 3/4 (m1 - m2) + 15/2 (m3 - m4).
 // Tile: 128 output channels x 16 units (one row quad x 64 steps), 8 waves; wave w owns channel tile w: 4 x 6 = 24 accumulators of
-// v_mfma_f32_16x16x4_f32 (96 registers) = ONE (tile, segment) item per wave.  Pipeline = conv_wino45x_kernel's: wave-private weights
-// by LDS-DMA into a 4-entry ring with counted s_waitcnt, two operand register sets, one barrier per 16-channel super-slab.  A ring
-// entry is a HALF-slot (4 ci x 16 co x 12 of the pass's 24 phases = 3 KB): 8 per super-slab, 24 MFMA groups of 4.
+// v_mfma_f32_16x16x4_f32 (96 registers) = ONE (tile, segment) item per wave.  One barrier per 16-channel super-slab; a super-slab is 8
+// half-slots (4 ci x 16 co x 12 of the pass's 24 phases) = 24 MFMA groups of 4.  The WEIGHT operand never touches LDS: the 96
+// accumulators leave room for a ring of 12 operand registers sets, loaded straight from global memory (L2-resident packed image, one
+// coalesced 1 KB load per wave and group, 12 groups ahead); LDS holds only the transformed activations (2 x 24 KB).  The first build
+// of this kernel staged the weights through a wave-private LDS-DMA ring like conv_wino45x_kernel: its ablations (tools/f45_ablate.py,
+// profiles/r05_f45_ablate.txt) charged 20 % of the time to the DMA and 18 % to the operand reads - LDS bandwidth was the limit.
 // Transform: thread = (ci, unit, half): waves 0-3 compute the first phase pair of the pass, waves 4-7 the second, for 4 input
 // channels x 16 units each - coefficients are wave-uniform.
 #include "common.h"
@@ -25,6 +28,10 @@
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef W85_ABL
+#define W85_ABL 0      // timing ablations only (tools/f45_ablate.py): 1 no transform arithmetic, 2 no row loads, 4 no weight loads,
+#endif                 // 8 no X reads, 16 no MFMA, 32 rows loaded by waves 0-3 only, 64 / 128 row loads that always hit L2 / L1 - results are wrong
 
 namespace {
 
@@ -41,12 +48,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
 #if __HIP_DEVICE_COMPILE__
     constexpr int KS = 16, KQ = 4, NU = 16, BN = 128;
     constexpr int XSZ = KS * NU * 6;                    // float4 per activation super-slab (16 ci x 16 units x 24 floats)
-    constexpr int WWV = KQ * 16 * 3;                    // float4 per wave and ring entry (4 ci x 16 co x 12 floats = 3 KB)
-    constexpr int WSL = 8 * WWV;
+#ifndef W85_RD
+#define W85_RD 12
+#endif
+    constexpr int RD = W85_RD;                          // weight register ring: groups in flight (a multiple of 3 that divides 24)
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     f32x4* smem = reinterpret_cast<f32x4*>(smem_f);
     f32x4* const Xb = smem;                             // X[2]
-    f32x4* const Wb = smem + 2 * XSZ;                   // ring[4][8 waves][4 ci][16 co][3]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -99,36 +107,19 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     }
     const int hsrc = (2 * s_ch + (s_tu == 15 ? 1 : 0)) * 4;               // bpermute byte index of row 0; row r adds 32
     const int xlds = ((wq4 * 4 + s_ch) * NU + s_tu) * 6 + half * 3;         // float4 index of this thread's 12 floats
-    // weight DMA (as conv_wino45x_kernel): chunk j of an entry = bytes [1024 j, 1024 j + 1024) of the wave's image [4 ci][16 co][48 B]
-    unsigned wvl[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int o = j * 1024 + lane * 16;
-        const int ci = o / 768;
-        wvl[j] = (unsigned)(ci * g.CoutP * 48 + (o - ci * 768));
-    }
-    const int wstep = KQ * g.CoutP * 48;                // next half-slot in the packed image [pass][ci quad][half][4 ci][CoutP][12]
+    // weights: global -> registers, one coalesced 1 KB load per group ([lk][l15] float4 of the packed image
+    // [pass][ci quad][half][co tile][pg][64 lanes][4]); the ring aw[RD] keeps RD groups in flight (the compiler counts vmcnt)
+    const int NT = g.CoutP >> 4;
+    const int wstep = NT * 3072;                        // next half-slot of this wave's channel tile
     const int sWend = 4 * g.CinP * g.CoutP * 48;
-    int sW = (co0 + wave * 16) * 48;
+    int sW = ((co0 >> 4) + wave) * 3072;
+    const unsigned wvo = (unsigned)(lane * 16);
     auto w_next = [&]() __attribute__((always_inline)) {
+        if (W85_ABL & 256) return;                      // (always the first half-slot: L1 hits)
         sW += wstep;
         sW = sW < sWend ? sW : sWend;
     };
-    f32x4* const Ww = Wb + wave * WWV;
-#ifndef W85_ABL
-#define W85_ABL 0      // timing ablations only (tools/f45_ablate.py): 1 no transform arithmetic, 2 no row loads, 4 no weight DMA,
-#endif                 // 8 no operand reads, 16 no MFMA, 32 rows loaded by waves 0-3 only, 64 / 128 row loads that always hit L2 / L1 - results are wrong
-#if W85_ABL & 4
-#define Y_DMA(rp, j)
-#else
-#define Y_DMA(rp, j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, LDS_PTR(Ww + (rp) * WSL + (j) * 64), 16, wvl[j], sW, 0, 0);
-#endif
 #define Y_FENCE __builtin_amdgcn_sched_barrier(0);
-#ifdef W85_SAFE
-#define Y_WAITVM(n) asm volatile("s_waitcnt vmcnt(0)");
-#else
-#define Y_WAITVM(n) asm volatile("s_waitcnt vmcnt(" #n ")");
-#endif
 
     f32x4 xv[8];
     xv[0] = xv[7] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -253,8 +244,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
         }
     };
 
-    // operand addresses (float4 units): A in the wave's ring part, B in X ([ci][unit][6 float4])
-    const int aoff = (lk * 16 + l15) * 3;
+    // B operand address (float4 units) in X ([ci][unit][6 float4]); the A operand comes straight from the weight ring in registers
     const int boff = (lk * NU + l15) * 6;
 
     // ---- prologue: super-slab 0 transformed into X[0], rows of super-slab 1 in flight, ring entries 0-2 loaded
@@ -263,12 +253,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     issue_halo(cA);
     issue_isc(cA);
     pS = pA;
+    f32x4 aw[RD];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        Y_DMA(i, 0)
-        Y_DMA(i, 1)
-        Y_DMA(i, 2)
-        w_next();
+    for (int i = 0; i < RD; ++i) {
+        aw[i] = (W85_ABL & 4) ? f32x4{1.f, 2.f, 3.f, 4.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo, sW + (i % 3) * 1024, 0));
+        if (i % 3 == 2) w_next();
     }
     Y_FENCE
     halo_permute();
@@ -280,7 +269,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     issue_isc(cA);
     pS = pA;
     Y_FENCE
-    asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)");        // the 9 weight DMAs landed (the 7 youngest loads - super-slab 1 - may stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)");
     __builtin_amdgcn_s_barrier();
     Y_FENCE
 
@@ -289,32 +278,30 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int p = 0; p < 12; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 av[2], bv[2];
-    if (W85_ABL & 8) av[0] = av[1] = bv[0] = bv[1] = f32x4{1.f, 2.f, 3.f, 4.f};
+    f32x4 bv[2];
+    bv[0] = bv[1] = f32x4{1.f, 2.f, 3.f, 4.f};
     // group G = 3 hs + pg of a super-slab (hs = half-slot 0..7 = (ci quad hs >> 1, phase half hs & 1), pg = 4 of its 12 phases):
-    //   [DMA chunk pg of half-slot hs + 3 into ring (hs + 3) & 3] [row / halo loads] [counted wait when a new half-slot is first read]
-    //   [reads of group G + 1 into the other operand set] [transform at G = 0] [4 MFMAs of group G]
-    // vmcnt bookkeeping (operations complete in order).  Per super-slab and wave, pass A: G0: D R R R | G1: D R R R | G2: D H |
-    // G3..G23: D (pass B: one more R in G0 and in G1).  Chunk 2 of half-slot hs + 1 was issued as the D of group 3 hs - 4; its first
-    // read is in group 3 hs + 2, after that group's D and loads: younger operations = loads of group 3 hs - 4 + (D + loads) of
-    // groups 3 hs - 3 .. 3 hs + 2 (pass A, the smaller count, is what the waits use):
-    //   hs = 0 (G2): groups 21, 22, 23, 0, 1, 2: 6 D + 3 + 3 + 1 = 13;  hs = 1 (G5): 23, 0, .., 5: 13;  hs = 2 (G8): H of G2 + 6 D = 7;
-    //   hs = 3 .. 7 (G11 .. G23): 6.
+    //   [row / halo loads] [X read of group G + 1 into the other operand set] [transform at G = 0] [4 MFMAs of group G]
+    //   [weight load of group G + RD into the ring entry the MFMAs just read]
 #if W85_ABL & 8
-#define Y_READ(c, Xp, hs, pg) asm volatile("" : "+v"(av[c]), "+v"(bv[c]));
+#define Y_READ(c, Xp, hs, pg) asm volatile("" : "+v"(bv[c]));
 #else
-#define Y_READ(c, Xp, hs, pg)                                          \
-    av[c] = Ww[((hs) & 3) * WSL + aoff + (pg)];                        \
-    bv[c] = (Xp)[boff + ((hs) >> 1) * KQ * NU * 6 + ((hs) & 1) * 3 + (pg)];
+#define Y_READ(c, Xp, hs, pg) bv[c] = (Xp)[boff + ((hs) >> 1) * KQ * NU * 6 + ((hs) & 1) * 3 + (pg)];
 #endif
-#define Y_MFMA(c, hs, pg)                                              \
+#ifdef W85_PRIO
+#define Y_PRIO(n) __builtin_amdgcn_s_setprio(n);
+#else
+#define Y_PRIO(n)
+#endif
+#define Y_MFMA(c, GN)                                                  \
     if (!(W85_ABL & 16))                                               \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
-        acc[(hs) & 1][4 * (pg) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i], bv[c][i], acc[(hs) & 1][4 * (pg) + i], 0, 0, 0);
-    // one group; GN = group index (compile time), NHS / NPG = half-slot and phase group of group GN + 1
-#define Y_G(GN, WAITN)                                                                                          \
-    Y_DMA((((GN) / 3) + 3) & 3, (GN) % 3)                                                                       \
-    Y_FENCE                                                                                                     \
+        acc[((GN) / 3) & 1][4 * ((GN) % 3) + i] =                      \
+            __builtin_amdgcn_mfma_f32_16x16x4f32(aw[(GN) % RD][i], bv[c][i], acc[((GN) / 3) & 1][4 * ((GN) % 3) + i], 0, 0, 0);
+#define Y_WLOAD(GN)                                                                                                          \
+    if (!(W85_ABL & 4)) aw[(GN) % RD] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo, sW + ((GN) % 3) * 1024, 0)); \
+    if constexpr ((GN) % 3 == 2) w_next();
+#define Y_G(GN)                                                                                                 \
     if constexpr ((GN) == 1) {                                                                                  \
         issue_rows(pA, cA, 4, 8);                                                                               \
         Y_FENCE                                                                                                 \
@@ -322,10 +309,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     if constexpr ((GN) == 2) {                                                                                  \
         issue_halo(cA);                                                                                         \
         Y_FENCE                                                                                                 \
-    }                                                                                                           \
-    if constexpr ((GN) % 3 == 2) {                                                                              \
-        w_next();                                                                                               \
-        Y_WAITVM(WAITN)                                                                                         \
     }                                                                                                           \
     if constexpr ((GN) < 23) {                                                                                  \
         Y_READ(((GN) + 1) & 1, Xs, ((GN) + 1) / 3, ((GN) + 1) % 3)                                              \
@@ -341,7 +324,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
         Y_FENCE                                                                                                 \
     }                                                                                                           \
     if constexpr ((GN) < 23) {                                                                                  \
-        Y_MFMA((GN) & 1, (GN) / 3, (GN) % 3)                                                                    \
+        Y_PRIO(1)                                                                                               \
+        Y_MFMA((GN) & 1, GN)                                                                                    \
+        Y_PRIO(0)                                                                                               \
+        Y_FENCE                                                                                                 \
+        Y_WLOAD(GN)                                                                                             \
         Y_FENCE                                                                                                 \
     }
 
@@ -351,24 +338,20 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     for (int S = 0; S < NS; ++S) {
         const f32x4* Xs = Xb + (S & 1) * XSZ;
         f32x4* Xw = Xb + ((S + 1) & 1) * XSZ;
-        Y_G(0, 0) Y_G(1, 0) Y_G(2, 13)
-        Y_G(3, 0) Y_G(4, 0) Y_G(5, 13)
-        Y_G(6, 0) Y_G(7, 0) Y_G(8, 7)
-        Y_G(9, 0) Y_G(10, 0) Y_G(11, 6)
-        Y_G(12, 0) Y_G(13, 0) Y_G(14, 6)
-        Y_G(15, 0) Y_G(16, 0) Y_G(17, 6)
-        Y_G(18, 0) Y_G(19, 0) Y_G(20, 6)
-        Y_G(21, 0) Y_G(22, 0)
-        // G23: D, wait for half-slot 0 of the next super-slab (issued at G17: 6 younger), barrier (X[(S + 1) & 1] complete, nobody
-        // reads X[S & 1] any more: the operands of this group are in registers), first reads of the next super-slab, 4 MFMAs
-        Y_G(23, 6)
+        Y_G(0) Y_G(1) Y_G(2) Y_G(3) Y_G(4) Y_G(5) Y_G(6) Y_G(7) Y_G(8) Y_G(9) Y_G(10) Y_G(11)
+        Y_G(12) Y_G(13) Y_G(14) Y_G(15) Y_G(16) Y_G(17) Y_G(18) Y_G(19) Y_G(20) Y_G(21) Y_G(22)
+        // G23: barrier (X[(S + 1) & 1] complete, nobody reads X[S & 1] any more: the operands of this group are in registers), first
+        // read of the next super-slab, 4 MFMAs
+        Y_G(23)
         asm volatile("s_waitcnt lgkmcnt(0)");
         __builtin_amdgcn_s_barrier();
         Y_FENCE
         Y_READ(0, Xw, 0, 0)
         halo_permute();
         Y_FENCE
-        Y_MFMA(1, 7, 2)
+        Y_MFMA(1, 23)
+        Y_FENCE
+        Y_WLOAD(23)
         Y_FENCE
         cM += KS;
         if (cM >= g.CinP) {
@@ -394,6 +377,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
 #undef Y_G
 #undef Y_MFMA
 #undef Y_READ
+#undef Y_WLOAD
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
 
     // ---- output: rows r = 0..3 from (M5, M6, M0, M7) = acc[0][0..5], acc[0][6..11], acc[1][0..5], acc[1][6..11]
@@ -426,8 +410,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
 #endif
 }
 
-// dst [2 passes][CinP / 4][2 halves][4 ci][CoutP][12]; entry 6 * fl + tp; phase pairs (A,0) = (p1,p2), (A,1) = (p3,p4),
-// (B,0) = (p5,p6), (B,1) = (p0,p7)
+// dst [2 passes][CinP / 4][2 halves][CoutP / 16][3 phase groups][4 ci][16 co][4]: one group's A operand of one wave = 1 KB, lane
+// (ci, co) its float4; entry 6 * fl + tp of the 12 phases of a half; phase pairs (A,0) = (p1,p2), (A,1) = (p3,p4), (B,0) = (p5,p6),
+// (B,1) = (p0,p7)
 __global__ void pack_wino85_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int tf, int CinP,
                                    int CoutP, long total) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -468,7 +453,7 @@ __global__ void pack_wino85_kernel(const float* __restrict__ w, float* __restric
     const double G3[6][3] = {{0.25, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                              {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
     const int fps[2][2][2] = {{{1, 2}, {3, 4}}, {{5, 6}, {0, 7}}};
-    float* d = dst + i * 12;
+    float d[12];
     for (int fl = 0; fl < 2; ++fl) {
         const int fp = fps[ps][hf][fl];
         double fw[3];
@@ -479,6 +464,11 @@ __global__ void pack_wino85_kernel(const float* __restrict__ w, float* __restric
         }
         for (int tp = 0; tp < 6; ++tp) d[6 * fl + tp] = (float)(G3[tp][0] * fw[0] + G3[tp][1] * fw[1] + G3[tp][2] * fw[2]);
     }
+    const long hslot = ((long)ps * (CinP / 4) + cq) * 2 + hf;
+    for (int pg = 0; pg < 3; ++pg) {
+        float* o = dst + ((((hslot * (CoutP / 16) + (co >> 4)) * 3 + pg) * 4 + c4) * 16 + (co & 15)) * 4;
+        for (int e = 0; e < 4; ++e) o[e] = d[4 * pg + e];
+    }
 }
 
 }  // namespace
@@ -486,7 +476,7 @@ __global__ void pack_wino85_kernel(const float* __restrict__ w, float* __restric
 extern "C" long babe_conv_packed_size_wino85(int Cout, int Cin, int transpose_flip) {
     const int co = transpose_flip ? Cin : Cout;
     const int ci = transpose_flip ? Cout : Cin;
-    return 48L * ((ci + 15) / 16 * 16) * ((co + 127) / 128 * 128);
+    return 48L * ((ci + 15) / 16 * 16) * ((co + 15) / 16 * 16);
 }
 
 extern "C" int babe_conv_pack_weights_wino85(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip,
@@ -494,7 +484,7 @@ extern "C" int babe_conv_pack_weights_wino85(const float* w, float* dst, int Cou
     BABE_CHECK_ARG(w && dst && Cout > 0 && Cin > 0 && KH == 5 && KW == 3, "conv_pack_weights_wino85: needs a (5,3) kernel");
     const int co = transpose_flip ? Cin : Cout;
     const int ci = transpose_flip ? Cout : Cin;
-    const int CinP = (ci + 15) / 16 * 16, CoutP = (co + 127) / 128 * 128;
+    const int CinP = (ci + 15) / 16 * 16, CoutP = (co + 15) / 16 * 16;
     const long total = 4L * CinP * CoutP;
     hipLaunchKernelGGL(pack_wino85_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, Cin,
                        transpose_flip, CinP, CoutP, total);
@@ -502,8 +492,10 @@ extern "C" int babe_conv_pack_weights_wino85(const float* w, float* dst, int Cou
     return BABE_OK;
 }
 
-/* 1 if the experimental F(4,5) x F(4,3) kernel can run this problem: 128-channel output tiles, 16-channel input slabs, T a multiple
- * of 4 and at least 64, one source, 16-byte aligned views */
+/* 1 if the F(4,5) x F(4,3) kernel can run this problem: 128-channel output tiles, 16-channel input slabs, T a multiple of 4 and at
+ * least 64, one source, 16-byte aligned views.  (A 96-channel tile - six multiplying waves of eight - was built and measured:
+ * 0.75x the F(2,5) x F(4,3) kernel on the 96-channel layers, whose 12 (tile, segment) items balance over the four SIMDs where
+ * this kernel's six cannot; profiles/r05_f45_check.txt.) */
 extern "C" int babe_conv2d_wino85_supported(const babe_conv_args* ap) {
     if (!ap) return 0;
     const babe_conv_args& a = *ap;
@@ -541,19 +533,13 @@ extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino8
     g.nquads = cdiv(cdiv(a.F, a.dil), 4);
     const double flops = babe_conv_flops(a);         // 48 multiplies per 16 outputs instead of 240: 0.2 of the direct count
     BabeProfScope prof(BABE_SLOT_CONV53_WINO85, babe_conv_bytes(a), flops, flops * 0.2, stream);
-    const size_t lds = (size_t)(2 * 16 * 16 * 6 + 4 * 8 * 4 * 16 * 3) * 16;   // 144 KB
-    static std::atomic<unsigned long long> attr{0};
-    if (babe_lds_optin(attr, {reinterpret_cast<const void*>(&conv_wino85_kernel<true>),
-                              reinterpret_cast<const void*>(&conv_wino85_kernel<false>)}, (int)lds) != hipSuccess) {
-        babe_set_error("conv2d_wino85: cannot opt in to %zu bytes of LDS", lds);
-        return BABE_ERR_HIP;
-    }
+    const size_t lds = (size_t)(2 * 16 * 16 * 6) * 16;                        // X[2]: 48 KB
     static const int xcd_order = [] { const char* e = getenv("BABE_W85_XCD"); return e ? atoi(e) : 1; }();
     g.xcd = xcd_order;
     g.ncb = a.Cout / 128;
     g.total = g.tiles_t * a.dil * g.nquads * g.ncb;
     g.per_xcd = (g.total + 7) / 8;
-    dim3 grid(g.tiles_t * a.dil * g.nquads, a.Cout / 128, a.B);
+    dim3 grid(g.tiles_t * a.dil * g.nquads, g.ncb, a.B);
     if (g.xcd) grid = dim3(8 * g.per_xcd, 1, a.B);
     if (a.in_scale) hipLaunchKernelGGL((conv_wino85_kernel<true>), grid, dim3(512), lds, (hipStream_t)stream, a, g, w_wino85);
     else hipLaunchKernelGGL((conv_wino85_kernel<false>), grid, dim3(512), lds, (hipStream_t)stream, a, g, w_wino85);
