@@ -410,6 +410,323 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
 #endif
 }
 
+// ---- 96- and 64-channel tiles: SPECIALISED waves.  With NW = 6 (4) channel tiles the eight waves do not split evenly over the four
+// SIMDs as multipliers (wave w and w + 4 share SIMD w & 3): instead waves 0 .. NW-1 ONLY multiply (weights ring, X reads, MFMAs,
+// epilogue) and waves NW .. 7 ONLY load and transform - all 16 ci x 16 units x 4 phases of a super-slab, 4 / (8 - NW) channel
+// quads per wave, both phase pairs per thread from ONE set of row loads.  NW = 6: SIMDs 0 and 1 host two multiplying waves, SIMDs 2
+// and 3 one multiplying wave plus a transform wave carrying four wave-shares of transform: about the same time.  NW = 4: every SIMD
+// hosts one of each.  The multiplying waves' memory queue holds weights only, the transform waves' rows only (two register sets: the
+// rows of super-slab S + 2 are in flight while S + 1 is transformed).  One barrier per super-slab, as in the 128-channel kernel.
+template <bool HAS_ISC, int NW>
+__global__ __launch_bounds__(512, 1) void conv_wino85s_kernel(babe_conv_args a, Wino85Geom g, const float* __restrict__ wq) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int KS = 16, KQ = 4, NU = 16, BN = 16 * NW, RD = 12;
+    constexpr int TW = 8 - NW, PPL = 4 / TW;            // transform waves; channel quads per transform wave
+    static_assert(NW == 6 || NW == 4, "tile width");
+    constexpr int XSZ = KS * NU * 6;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    f32x4* const Xb = reinterpret_cast<f32x4*>(smem_f);  // X[2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (g.xcd) {                                        // XCD-contiguous tile order (see conv_wino85_kernel)
+        const int lin = (bx & 7) * g.per_xcd + (bx >> 3);
+        if ((bx >> 3) >= g.per_xcd || lin >= g.total) return;
+        by = lin % g.ncb;
+        bx = lin / g.ncb;
+    }
+    const int co0 = by * BN;
+    const int nQ = a.dil * g.nquads;
+    const int tile_t = g.xcd ? bx / nQ : bx % g.tiles_t;
+    const int Q = g.xcd ? bx % nQ : bx / g.tiles_t;
+    const int t0 = tile_t * 64;
+    const int cls = Q / g.nquads;
+    const int fa = Q < a.dil * g.nquads ? cls + 4 * (Q - cls * g.nquads) * a.dil : a.F + 8 * a.dil;
+    const int NS = 2 * (g.CinP / KS);                   // super-slabs (even)
+
+    if (wave >= NW) {
+        // ================= transform waves =================
+        const float* p1 = a.in + (long)b * a.in_bs;
+        const int cs1 = (int)a.in_cs;
+        const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p1, 0, a.Cin * cs1 * 4, 0x00020000);
+        const int vw0 = (wave - NW) * PPL;              // first channel quad of this wave
+        const int s_tu = lane & 15, s_ch = lane >> 4;
+        const int s_t = t0 + 4 * s_tu;
+        const unsigned chb = (unsigned)(s_ch * cs1 * 4);
+        unsigned er[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int fr = fa + (r - 2) * a.dil;
+            const bool ok = fr >= 0 && fr < a.F && s_t < a.T;
+            er[r] = ok ? (unsigned)((fr * a.T + s_t) * 4) + chb : OOBH;
+        }
+        unsigned ehalo = OOBH;
+        {
+            const int hr = lane >> 3, hc = (lane >> 1) & 3, hs = lane & 1;
+            const int fr = fa + (hr - 2) * a.dil;
+            const int th = t0 + (hs ? 64 : -1);
+            if (fr >= 0 && fr < a.F && th >= 0 && th < a.T) ehalo = (unsigned)((fr * a.T + th) * 4 + hc * cs1 * 4);
+        }
+        const int hsrc = (2 * s_ch + (s_tu == 15 ? 1 : 0)) * 4;
+        f32x4 xv[2][PPL][8];
+        float xhl[2][PPL], xsc[2][PPL];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                xv[i][p][0] = xv[i][p][7] = f32x4{0.f, 0.f, 0.f, 0.f};
+                xsc[i][p] = 1.f;
+            }
+        auto dpp_shr1 = [](float old, float src) __attribute__((always_inline)) {
+            asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+            return old;
+        };
+        auto dpp_shl1 = [](float old, float src) __attribute__((always_inline)) {
+            asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+            return old;
+        };
+        auto tt = [](const float (&E)[6], float (&U)[6]) {
+            const float e = E[4] - 4.f * E[2], o = E[3] - 4.f * E[1];
+            const float e2 = E[4] - E[2], o2 = E[3] - E[1];
+            U[0] = 4.f * E[0] + (E[4] - 5.f * E[2]);
+            U[1] = e + o;
+            U[2] = e - o;
+            U[3] = e2 + 2.f * o2;
+            U[4] = e2 - 2.f * o2;
+            U[5] = 4.f * E[1] + (E[5] - 5.f * E[3]);
+        };
+        // the rows of super-slab (ps, ci0) into register set `st` (rows 0 and 7 in pass B only), its halo and input scale
+        auto issue = [&](int st, int ps, int ci0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                const int so = (ci0 + 4 * (vw0 + p)) * cs1 * 4;
+#pragma unroll
+                for (int r = 1; r < 7; ++r) xv[st][p][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[r], so, 0));
+                if (ps == 1) {
+                    xv[st][p][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[0], so, 0));
+                    xv[st][p][7] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, er[7], so, 0));
+                }
+                xhl[st][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ehalo, so, 0));
+                if (HAS_ISC) xsc[st][p] = a.in_scale[(long)b * a.Cin + ci0 + 4 * (vw0 + p) + s_ch];
+            }
+        };
+        // register set `st` (rows of a pass-`ps` super-slab) -> X buffer `buf`: both phase pairs of the pass for this thread's
+        // (ci, unit) pairs; the arithmetic of conv_wino85_kernel's store_act, term for term
+        auto transform = [&](int st, int ps, f32x4* buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                float xh[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(xh[r]) : "v"(hsrc), "v"(xhl[st][p]), "n"(32 * r));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]), "+v"(xh[5]), "+v"(xh[6]), "+v"(xh[7]));
+                const int xl = (((vw0 + p) * 4 + s_ch) * NU + s_tu) * 6;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int sel = ps * 2 + hf;
+                    auto pick = [&](unsigned v0, unsigned v1, unsigned v2, unsigned v3) __attribute__((always_inline)) {
+                        return __builtin_bit_cast(float, sel == 0 ? v0 : (sel == 1 ? v1 : (sel == 2 ? v2 : v3)));
+                    };
+                    const float c2 = pick(0x3f800000u, 0x3e800000u, 0x40800000u, 0x40a80000u);        // 1.0 0.25 4.0 5.25
+                    const float c4 = pick(0xc0880000u, 0xbfa00000u, 0xc0a00000u, 0xc0a80000u);        // -4.25 -1.25 -5.0 -5.25
+                    const float c1 = pick(0x3f800000u, 0x3f000000u, 0x40000000u, 0xbf800000u);        // 1.0 0.5 2.0 -1.0
+                    const float c3 = pick(0xc0880000u, 0xc0200000u, 0xc0200000u, 0x40a80000u);        // -4.25 -2.5 -2.5 5.25
+                    const float c5 = pick(0x3f800000u, 0x40000000u, 0x3f000000u, 0xc0a80000u);        // 1.0 2.0 0.5 -5.25
+                    const bool special = sel == 3;
+                    float Ea[6], Eb[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        float d[8];
+#pragma unroll
+                        for (int r = 1; r < 7; ++r)
+                            d[r] = j == 0 ? dpp_shr1(xh[r], xv[st][p][r][3]) : (j == 5 ? dpp_shl1(xh[r], xv[st][p][r][0]) : xv[st][p][r][j - 1]);
+                        float X = c2 * d[2] + (c4 * d[4] + d[6]);
+                        float Y = c1 * d[1] + (c3 * d[3] + c5 * d[5]);
+                        if (special) {
+                            d[0] = j == 0 ? dpp_shr1(xh[0], xv[st][p][0][3]) : (j == 5 ? dpp_shl1(xh[0], xv[st][p][0][0]) : xv[st][p][0][j - 1]);
+                            d[7] = j == 0 ? dpp_shr1(xh[7], xv[st][p][7][3]) : (j == 5 ? dpp_shl1(xh[7], xv[st][p][7][0]) : xv[st][p][7][j - 1]);
+                            X = X - d[0];
+                            Y = Y + d[7];
+                            Ea[j] = X;
+                            Eb[j] = Y;
+                        } else {
+                            Ea[j] = X + Y;
+                            Eb[j] = X - Y;
+                        }
+                    }
+                    if (HAS_ISC) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            Ea[j] *= xsc[st][p];
+                            Eb[j] *= xsc[st][p];
+                        }
+                    }
+                    float Ua[6], Ub[6];
+                    tt(Ea, Ua);
+                    tt(Eb, Ub);
+                    buf[xl + hf * 3] = f32x4{Ua[0], Ua[1], Ua[2], Ua[3]};
+                    buf[xl + hf * 3 + 1] = f32x4{Ua[4], Ua[5], Ub[0], Ub[1]};
+                    buf[xl + hf * 3 + 2] = f32x4{Ub[2], Ub[3], Ub[4], Ub[5]};
+                }
+            }
+        };
+        auto advance = [&](int& ps, int& ci0) __attribute__((always_inline)) {    // next super-slab, clamped at the last one
+            int nc = ci0 + KS, np = ps;
+            if (nc >= g.CinP) {
+                nc = 0;
+                ++np;
+            }
+            if (np <= 1) {
+                ps = np;
+                ci0 = nc;
+            }
+        };
+        // super-slab s lives in register set s & 1; (pT, cT) = the slab transformed next, (pL, cL) = the slab loaded next
+        int pT = 0, cT = 0, pL = 0, cL = 0;
+        issue(0, pL, cL);
+        advance(pL, cL);
+        issue(1, pL, cL);
+        advance(pL, cL);
+        transform(0, pT, Xb);                              // super-slab 0 -> X[0]
+        advance(pT, cT);
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        __builtin_amdgcn_s_barrier();
+        for (int S = 0; S < NS; S += 2) {
+            // iteration S (even): set 0 is free (slab S was transformed last time): rows of slab S + 2; transform slab S + 1 (set 1)
+            issue(0, pL, cL);
+            advance(pL, cL);
+            transform(1, pT, Xb + XSZ);
+            advance(pT, cT);
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            __builtin_amdgcn_s_barrier();
+            // iteration S + 1: rows of slab S + 3 into set 1; transform slab S + 2 (set 0) -> X[0]
+            issue(1, pL, cL);
+            advance(pL, cL);
+            transform(0, pT, Xb);
+            advance(pT, cT);
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ================= multiplying waves =================
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, 4 * g.CinP * g.CoutP * 48, 0x00020000);
+    const int NT = g.CoutP >> 4;
+    const int wstep = NT * 3072;
+    const int sWend = 4 * g.CinP * g.CoutP * 48;
+    int sW = ((co0 >> 4) + wave) * 3072;
+    const unsigned wvo = (unsigned)(lane * 16);
+    auto w_next = [&]() __attribute__((always_inline)) {
+        sW += wstep;
+        sW = sW < sWend ? sW : sWend;
+    };
+    const int boff = (lk * NU + l15) * 6;
+    f32x4 aw[RD];
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+        aw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo, sW + (i % 3) * 1024, 0));
+        if (i % 3 == 2) w_next();
+    }
+    f32x4 acc[2][12];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 12; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bv[2];
+    __builtin_amdgcn_s_barrier();                          // X[0] is complete
+    Y_FENCE
+#define Z_READ(c, Xp, hs, pg) bv[c] = (Xp)[boff + ((hs) >> 1) * KQ * NU * 6 + ((hs) & 1) * 3 + (pg)];
+#define Z_MFMA(c, GN)                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
+        acc[((GN) / 3) & 1][4 * ((GN) % 3) + i] =                      \
+            __builtin_amdgcn_mfma_f32_16x16x4f32(aw[(GN) % RD][i], bv[c][i], acc[((GN) / 3) & 1][4 * ((GN) % 3) + i], 0, 0, 0);
+#define Z_WLOAD(GN)                                                                                                          \
+    aw[(GN) % RD] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo, sW + ((GN) % 3) * 1024, 0)); \
+    if constexpr ((GN) % 3 == 2) w_next();
+#define Z_G(GN)                                                        \
+    Z_READ(((GN) + 1) & 1, Xs, ((GN) + 1) / 3, ((GN) + 1) % 3)         \
+    Y_FENCE                                                            \
+    Z_MFMA((GN) & 1, GN)                                               \
+    Y_FENCE                                                            \
+    Z_WLOAD(GN)                                                        \
+    Y_FENCE
+    Z_READ(0, Xb, 0, 0)
+    int cM = 0, pM = 0;
+    for (int S = 0; S < NS; ++S) {
+        const f32x4* Xs = Xb + (S & 1) * XSZ;
+        const f32x4* Xw = Xb + ((S + 1) & 1) * XSZ;
+        Z_G(0) Z_G(1) Z_G(2) Z_G(3) Z_G(4) Z_G(5) Z_G(6) Z_G(7) Z_G(8) Z_G(9) Z_G(10) Z_G(11)
+        Z_G(12) Z_G(13) Z_G(14) Z_G(15) Z_G(16) Z_G(17) Z_G(18) Z_G(19) Z_G(20) Z_G(21) Z_G(22)
+        // G23: its operands are in registers; barrier (X[(S + 1) & 1] complete, nobody reads X[S & 1] any more)
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        __builtin_amdgcn_s_barrier();
+        Y_FENCE
+        Z_READ(0, Xw, 0, 0)
+        Y_FENCE
+        Z_MFMA(1, 23)
+        Y_FENCE
+        Z_WLOAD(23)
+        Y_FENCE
+        cM += KS;
+        if (cM >= g.CinP) {
+            cM = 0;
+            if (pM == 0) {
+                asm volatile("s_nop 15\n\ts_nop 15");
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float m1 = acc[0][p][e], m2 = acc[0][6 + p][e], m3 = acc[1][p][e], m4 = acc[1][6 + p][e];
+                        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                        acc[0][p][e] = (2.f * s12 + d12) + (8.f * s34 + 2.f * d34);
+                        acc[0][6 + p][e] = (2.f * s12 - d12) + (8.f * s34 - 2.f * d34);
+                        acc[1][p][e] = -3.f * s12 - 15.f * s34;
+                        acc[1][6 + p][e] = 0.75f * d12 + 7.5f * d34;
+                    }
+            }
+            ++pM;
+        }
+    }
+#undef Z_G
+#undef Z_MFMA
+#undef Z_READ
+#undef Z_WLOAD
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+
+    const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
+    const int t = t0 + 4 * l15;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const int f = fa + row * a.dil;
+        const bool pv = f < a.F && t < a.T;
+        const long sp = pv ? (long)f * a.T + t : 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int co = co0 + wave * 16 + 4 * lk + kk;
+            const float os = has_os ? a.oscale[b * a.Cout + co] : 1.f;
+            const f32x4 rr = (has_res && pv) ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)co * a.res_cs + sp)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            float m[6];
+#pragma unroll
+            for (int tp = 0; tp < 6; ++tp) {
+                const float M5 = acc[0][tp][kk], M6 = acc[0][6 + tp][kk], M0 = acc[1][tp][kk], M7 = acc[1][6 + tp][kk];
+                m[tp] = row == 0 ? (M5 + M6) + M0 : (row == 1 ? 0.5f * (M5 - M6) : (row == 2 ? 0.25f * (M5 + M6) : 0.125f * (M5 - M6) + M7));
+            }
+            const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+            f32x4 y = {m[0] + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + m[5]};
+            const float sc = a.alpha * os;
+            y = y * sc + a.rbeta * rr;
+            if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
+        }
+    }
+#endif
+}
+
 // dst [2 passes][CinP / 4][2 halves][CoutP / 16][3 phase groups][4 ci][16 co][4]: one group's A operand of one wave = 1 KB, lane
 // (ci, co) its float4; entry 6 * fl + tp of the 12 phases of a half; phase pairs (A,0) = (p1,p2), (A,1) = (p3,p4), (B,0) = (p5,p6),
 // (B,1) = (p0,p7)
@@ -501,7 +818,7 @@ extern "C" int babe_conv2d_wino85_supported(const babe_conv_args* ap) {
     const babe_conv_args& a = *ap;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (a.KH != 5 || a.KW != 3 || a.T % 4 != 0 || a.T < 64 || a.dil < 1) return 0;
-    if (a.Cin < 16 || a.Cin % 16 != 0 || a.Cout % 128 != 0) return 0;
+    if (a.Cin < 16 || a.Cin % 16 != 0 || (a.Cout % 128 != 0 && a.Cout % 96 != 0 && a.Cout % 64 != 0)) return 0;
     if (!al16(a.in) || a.in_bs % 4 || a.in_cs % 4 || a.in2) return 0;
     if (!al16(a.out) || a.out_bs % 4 || a.out_cs % 4) return 0;
     if (a.res && (!al16(a.res) || a.res_bs % 4 || a.res_cs % 4)) return 0;
@@ -535,14 +852,25 @@ extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino8
     BabeProfScope prof(BABE_SLOT_CONV53_WINO85, babe_conv_bytes(a), flops, flops * 0.2, stream);
     const size_t lds = (size_t)(2 * 16 * 16 * 6) * 16;                        // X[2]: 48 KB
     static const int xcd_order = [] { const char* e = getenv("BABE_W85_XCD"); return e ? atoi(e) : 1; }();
+    const int bn = a.Cout % 128 == 0 ? 128 : (a.Cout % 96 == 0 ? 96 : 64);
     g.xcd = xcd_order;
-    g.ncb = a.Cout / 128;
+    g.ncb = a.Cout / bn;
     g.total = g.tiles_t * a.dil * g.nquads * g.ncb;
     g.per_xcd = (g.total + 7) / 8;
     dim3 grid(g.tiles_t * a.dil * g.nquads, g.ncb, a.B);
     if (g.xcd) grid = dim3(8 * g.per_xcd, 1, a.B);
-    if (a.in_scale) hipLaunchKernelGGL((conv_wino85_kernel<true>), grid, dim3(512), lds, (hipStream_t)stream, a, g, w_wino85);
-    else hipLaunchKernelGGL((conv_wino85_kernel<false>), grid, dim3(512), lds, (hipStream_t)stream, a, g, w_wino85);
+    const hipStream_t st = (hipStream_t)stream;
+    const bool isc = a.in_scale != nullptr;
+    if (bn == 128) {
+        if (isc) hipLaunchKernelGGL((conv_wino85_kernel<true>), grid, dim3(512), lds, st, a, g, w_wino85);
+        else hipLaunchKernelGGL((conv_wino85_kernel<false>), grid, dim3(512), lds, st, a, g, w_wino85);
+    } else if (bn == 96) {
+        if (isc) hipLaunchKernelGGL((conv_wino85s_kernel<true, 6>), grid, dim3(512), lds, st, a, g, w_wino85);
+        else hipLaunchKernelGGL((conv_wino85s_kernel<false, 6>), grid, dim3(512), lds, st, a, g, w_wino85);
+    } else {
+        if (isc) hipLaunchKernelGGL((conv_wino85s_kernel<true, 4>), grid, dim3(512), lds, st, a, g, w_wino85);
+        else hipLaunchKernelGGL((conv_wino85s_kernel<false, 4>), grid, dim3(512), lds, st, a, g, w_wino85);
+    }
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

@@ -106,10 +106,10 @@ class PackedConv:
                 check(L.babe_conv_pack_weights_wino45(ptr(w), ptr(self.bwd_wino45), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino45")
         self.fwd_wino85 = self.bwd_wino85 = None
         if self.KH == 5 and self.KW == 3 and WINOGRAD85:
-            if self.Cin % 16 == 0 and self.Cout % 128 == 0:
+            if self.Cin % 16 == 0 and self.Cout % 32 == 0 and (self.Cout % 128 == 0 or self.Cout % 96 == 0 or self.Cout % 64 == 0):   # its tile widths
                 self.fwd_wino85 = torch.empty(L.babe_conv_packed_size_wino85(self.Cout, self.Cin, 0), device=w.device)
                 check(L.babe_conv_pack_weights_wino85(ptr(w), ptr(self.fwd_wino85), self.Cout, self.Cin, self.KH, self.KW, 0, stream()), "pack_wino85")
-            if self.Cout % 16 == 0 and self.Cin % 128 == 0:
+            if self.Cout % 16 == 0 and (self.Cin % 128 == 0 or self.Cin % 96 == 0 or self.Cin % 64 == 0):
                 self.bwd_wino85 = torch.empty(L.babe_conv_packed_size_wino85(self.Cout, self.Cin, 1), device=w.device)
                 check(L.babe_conv_pack_weights_wino85(ptr(w), ptr(self.bwd_wino85), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino85")
 

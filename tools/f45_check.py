@@ -15,7 +15,8 @@ def rel(a, b):
 
 bad = 0
 for (B, Cin, Cout, Fq, T, dil) in [(1, 128, 128, 48, 128, 2), (1, 256, 256, 28, 64, 4), (2, 128, 256, 40, 100, 1), (1, 96, 128, 56, 64, 8),
-                                   (1, 128, 128, 24, 192, 16), (1, 256, 128, 448, 64, 64)]:
+                                   (1, 128, 128, 24, 192, 16), (1, 256, 128, 448, 64, 64), (1, 96, 96, 40, 128, 2), (2, 128, 192, 20, 68, 1),
+                                   (1, 64, 64, 24, 128, 1), (2, 32, 64, 36, 100, 3), (1, 96, 64, 20, 64, 4)]:
     g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + T + dil)
     x = torch.randn(B, Cin, Fq, T, generator=g)
     w = torch.randn(Cout, Cin, 5, 3, generator=g) / math.sqrt(Cin * 15)
@@ -57,7 +58,7 @@ def bench(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 print("timing, forward, us (F45 / production nested kernel), algorithmic TFLOP/s")
-for name, C, Fq, T, dil in [("enc3", 128, 256, 512, 4), ("enc4", 128, 320, 256, 8), ("dec5", 128, 384, 128, 8), ("enc5", 256, 384, 128, 8), ("enc6", 256, 448, 64, 8),
+for name, C, Fq, T, dil in [("enc0", 64, 64, 4096, 2), ("dec1", 64, 128, 2048, 4), ("enc1", 96, 128, 2048, 2), ("enc2", 96, 192, 1024, 4), ("dec3", 96, 256, 512, 8), ("enc3", 128, 256, 512, 4), ("enc4", 128, 320, 256, 8), ("dec5", 128, 384, 128, 8), ("enc5", 256, 384, 128, 8), ("enc6", 256, 448, 64, 8),
                             ("enc6.d64", 256, 448, 64, 64), ("enc5.d64", 256, 384, 128, 64)]:
     for B in (1, 2):
         g = torch.Generator().manual_seed(1)
