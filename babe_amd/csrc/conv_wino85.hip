@@ -20,8 +20,13 @@
 // coalesced 1 KB load per wave and group, 12 groups ahead); LDS holds only the transformed activations (2 x 24 KB).  The first build
 // of this kernel staged the weights through a wave-private LDS-DMA ring like conv_wino45x_kernel: its ablations (tools/f45_ablate.py,
 // profiles/r05_f45_ablate.txt) charged 20 % of the time to the DMA and 18 % to the operand reads - LDS bandwidth was the limit.
-// Transform: thread = (ci, unit, half): waves 0-3 compute the first phase pair of the pass, waves 4-7 the second, for 4 input
-// channels x 16 units each - coefficients are wave-uniform.
+// Transform (128-channel kernel): thread = (ci, unit, half): waves 0-3 compute the first phase pair of the pass, waves 4-7 the second,
+// for 4 input channels x 16 units each - coefficients are wave-uniform.
+// 96- and 64-channel tiles: conv_wino85s_kernel below - waves 0 .. NW-1 only multiply, waves NW .. 7 only load and transform, which
+// balances the four SIMDs where six (four) multiplying waves alone cannot.  All three produce the same sums in the same order for a
+// given (co, output): a conv run as 64-channel tiles equals the same conv run as one 128-channel tile bit for bit.
+// Measured (profiles/r05_f45_check.txt, MI355X, us per launch F45 / F(2,5)xF(4,3)): 128 ch 164 / 205, 256 ch 273 / 350, 96 ch
+// 212 / 268, 64 ch 109 / 145; whole job 2.136 -> 2.40 audio-sec/s.
 #include "common.h"
 #include "../../include/babe_hip.h"
 #include "prof.h"
@@ -42,6 +47,134 @@ struct Wino85Geom {
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr unsigned OOBH = 0xC0000000u;
+
+// ---- arithmetic shared by the two kernels, written with explicit fused multiply-adds and contraction off, so that the 128-channel
+// kernel and the specialised-wave kernel round identically (tests/test_gpu_ops.py::test_f45_tile_widths_are_bit_identical)
+__device__ __forceinline__ float w85_dpp_shr1(float old, float src) {
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+    return old;
+}
+__device__ __forceinline__ float w85_dpp_shl1(float old, float src) {
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+    return old;
+}
+// time transform B^T of F(4,3) (points 0, +-1, +-2, inf) of six samples
+__device__ __forceinline__ void w85_tt(const float (&E)[6], float (&U)[6]) {
+#pragma clang fp contract(off)
+    const float e = __builtin_fmaf(-4.f, E[2], E[4]), o = __builtin_fmaf(-4.f, E[1], E[3]);
+    const float e2 = E[4] - E[2], o2 = E[3] - E[1];
+    U[0] = __builtin_fmaf(4.f, E[0], __builtin_fmaf(-5.f, E[2], E[4]));
+    U[1] = e + o;
+    U[2] = e - o;
+    U[3] = __builtin_fmaf(2.f, o2, e2);
+    U[4] = __builtin_fmaf(-2.f, o2, e2);
+    U[5] = __builtin_fmaf(4.f, E[1], __builtin_fmaf(-5.f, E[3], E[5]));
+}
+// one thread's (ci, unit): patch rows xv[0..7] (4 samples each), halo samples xh[0..7] (left neighbour's last / right neighbour's
+// first sample, by DPP inside the 16-lane row of units) -> the 12 transformed values of phase pair sel = 2 pass + half:
+//   X = c0 d0 + c2 d2 + c4 d4 + d6,  Y = c1 d1 + c3 d3 + c5 d5 + c7 d7,  (Ea, Eb) = (X + Y, X - Y)   [sel 3: (X, Y)]
+//   sel 0 p1/p2: c2 1     c4 -17/4  c1 1    c3 -17/4  c5 1
+//   sel 1 p3/p4: c2 1/4   c4 -5/4   c1 1/2  c3 -5/2   c5 2
+//   sel 2 p5/p6: c2 4     c4 -5     c1 2    c3 -5/2   c5 1/2
+//   sel 3 p0/p7: c0 -1 c2 21/4 c4 -21/4   c1 -1 c3 21/4 c5 -21/4 c7 1
+// (coefficients selected as integers so that they stay in scalar registers: a float ?: chain became a tree of branches)
+template <bool HAS_ISC>
+__device__ __forceinline__ void w85_transform(const f32x4 (&xv)[8], const float (&xh)[8], int sel, float xsc, f32x4& o0, f32x4& o1,
+                                              f32x4& o2) {
+#pragma clang fp contract(off)
+    auto pick = [&](unsigned v0, unsigned v1, unsigned v2, unsigned v3) __attribute__((always_inline)) {
+        return __builtin_bit_cast(float, sel == 0 ? v0 : (sel == 1 ? v1 : (sel == 2 ? v2 : v3)));
+    };
+    const float c2 = pick(0x3f800000u, 0x3e800000u, 0x40800000u, 0x40a80000u);        // 1.0 0.25 4.0 5.25
+    const float c4 = pick(0xc0880000u, 0xbfa00000u, 0xc0a00000u, 0xc0a80000u);        // -4.25 -1.25 -5.0 -5.25
+    const float c1 = pick(0x3f800000u, 0x3f000000u, 0x40000000u, 0xbf800000u);        // 1.0 0.5 2.0 -1.0
+    const float c3 = pick(0xc0880000u, 0xc0200000u, 0xc0200000u, 0x40a80000u);        // -4.25 -2.5 -2.5 5.25
+    const float c5 = pick(0x3f800000u, 0x40000000u, 0x3f000000u, 0xc0a80000u);        // 1.0 2.0 0.5 -5.25
+    const bool special = sel == 3;                      // (wave-uniform: the only user of rows 0 and 7)
+    float Ea[6], Eb[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float d[8];
+#pragma unroll
+        for (int r = 1; r < 7; ++r) d[r] = j == 0 ? w85_dpp_shr1(xh[r], xv[r][3]) : (j == 5 ? w85_dpp_shl1(xh[r], xv[r][0]) : xv[r][j - 1]);
+        float X = __builtin_fmaf(c2, d[2], __builtin_fmaf(c4, d[4], d[6]));
+        float Y = __builtin_fmaf(c1, d[1], __builtin_fmaf(c3, d[3], c5 * d[5]));
+        if (special) {
+            d[0] = j == 0 ? w85_dpp_shr1(xh[0], xv[0][3]) : (j == 5 ? w85_dpp_shl1(xh[0], xv[0][0]) : xv[0][j - 1]);
+            d[7] = j == 0 ? w85_dpp_shr1(xh[7], xv[7][3]) : (j == 5 ? w85_dpp_shl1(xh[7], xv[7][0]) : xv[7][j - 1]);
+            Ea[j] = X - d[0];
+            Eb[j] = Y + d[7];
+        } else {
+            Ea[j] = X + Y;
+            Eb[j] = X - Y;
+        }
+    }
+    if (HAS_ISC) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            Ea[j] *= xsc;
+            Eb[j] *= xsc;
+        }
+    }
+    float Ua[6], Ub[6];
+    w85_tt(Ea, Ua);
+    w85_tt(Eb, Ub);
+    o0 = f32x4{Ua[0], Ua[1], Ua[2], Ua[3]};
+    o1 = f32x4{Ua[4], Ua[5], Ub[0], Ub[1]};
+    o2 = f32x4{Ub[2], Ub[3], Ub[4], Ub[5]};
+}
+// pass boundary: carry the finished phases (p1, p2, p3, p4) into the accumulators of (p5, p6, p0, p7)
+__device__ __forceinline__ void w85_carry(f32x4 (&acc)[2][12]) {
+#pragma clang fp contract(off)
+    asm volatile("s_nop 15\n\ts_nop 15");
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float m1 = acc[0][p][e], m2 = acc[0][6 + p][e], m3 = acc[1][p][e], m4 = acc[1][6 + p][e];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            acc[0][p][e] = __builtin_fmaf(2.f, s12, d12) + __builtin_fmaf(8.f, s34, 2.f * d34);          // 3 m1 + m2 + 10 m3 + 6 m4
+            acc[0][6 + p][e] = __builtin_fmaf(2.f, s12, -d12) + __builtin_fmaf(8.f, s34, -2.f * d34);    // m1 + 3 m2 + 6 m3 + 10 m4
+            acc[1][p][e] = __builtin_fmaf(-3.f, s12, -15.f * s34);
+            acc[1][6 + p][e] = __builtin_fmaf(0.75f, d12, 7.5f * d34);
+        }
+}
+// output: rows r = 0..3 from (M5, M6, M0, M7) = acc[0][0..5], acc[0][6..11], acc[1][0..5], acc[1][6..11]; cot0 = the wave's first channel
+__device__ __forceinline__ void w85_epilogue(const babe_conv_args& a, const f32x4 (&acc)[2][12], int b, int cot0, int fa, int t0, int lk,
+                                             int l15) {
+#pragma clang fp contract(off)
+    const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
+    const int t = t0 + 4 * l15;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const int f = fa + row * a.dil;
+        const bool pv = f < a.F && t < a.T;
+        const long sp = pv ? (long)f * a.T + t : 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int co = cot0 + 4 * lk + kk;
+            const float os = has_os ? a.oscale[b * a.Cout + co] : 1.f;
+            const f32x4 rr = (has_res && pv) ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)co * a.res_cs + sp)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            float m[6];
+#pragma unroll
+            for (int tp = 0; tp < 6; ++tp) {
+                const float M5 = acc[0][tp][kk], M6 = acc[0][6 + tp][kk], M0 = acc[1][tp][kk], M7 = acc[1][6 + tp][kk];
+                m[tp] = row == 0 ? (M5 + M6) + M0 : (row == 1 ? 0.5f * (M5 - M6) : (row == 2 ? 0.25f * (M5 + M6) : __builtin_fmaf(0.125f, M5 - M6, M7)));
+            }
+            const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+            const float y0 = m[0] + s12 + s34, y1 = __builtin_fmaf(2.f, d34, d12), y2 = __builtin_fmaf(4.f, s34, s12),
+                        y3 = __builtin_fmaf(8.f, d34, d12) + m[5];
+            const float sc = a.alpha * os;
+            f32x4 y;
+            y[0] = __builtin_fmaf(y0, sc, a.rbeta * rr[0]);
+            y[1] = __builtin_fmaf(y1, sc, a.rbeta * rr[1]);
+            y[2] = __builtin_fmaf(y2, sc, a.rbeta * rr[2]);
+            y[3] = __builtin_fmaf(y3, sc, a.rbeta * rr[3]);
+            if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
+        }
+    }
+}
 
 template <bool HAS_ISC>
 __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, Wino85Geom g, const float* __restrict__ wq) {
@@ -150,34 +283,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     auto issue_isc = [&](int ci0) __attribute__((always_inline)) {
         if (HAS_ISC) xsc = a.in_scale[(long)b * a.Cin + ci0 + 4 * wq4 + s_ch];
     };
-    auto dpp_shr1 = [](float old, float src) __attribute__((always_inline)) {
-        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
-        return old;
-    };
-    auto dpp_shl1 = [](float old, float src) __attribute__((always_inline)) {
-        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
-        return old;
-    };
-    auto tt = [](const float (&E)[6], float (&U)[6]) {
-        const float e = E[4] - 4.f * E[2], o = E[3] - 4.f * E[1];
-        const float e2 = E[4] - E[2], o2 = E[3] - E[1];
-        U[0] = 4.f * E[0] + (E[4] - 5.f * E[2]);
-        U[1] = e + o;
-        U[2] = e - o;
-        U[3] = e2 + 2.f * o2;
-        U[4] = e2 - 2.f * o2;
-        U[5] = 4.f * E[1] + (E[5] - 5.f * E[3]);
-    };
     auto halo_permute = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(xh[r]) : "v"(hsrc), "v"(xhl), "n"(32 * r));
     };
-    // X = c0 d0 + c2 d2 + c4 d4 + d6,  Y = c1 d1 + c3 d3 + c5 d5 + c7 d7,  (Ea, Eb) = (X + al Y, be X + ga Y); wave-uniform
-    //   (A, 0) p1/p2: c2 1     c4 -17/4  c1 1    c3 -17/4  c5 1    al 1  be 1  ga -1
-    //   (A, 1) p3/p4: c2 1/4   c4 -5/4   c1 1/2  c3 -5/2   c5 2
-    //   (B, 0) p5/p6: c2 4     c4 -5     c1 2    c3 -5/2   c5 1/2
-    //   (B, 1) p0/p7: c0 -1 c2 21/4 c4 -21/4   c1 -1 c3 21/4 c5 -21/4 c7 1    al 0  be 0  ga 1
     auto store_act = [&](f32x4* buf) __attribute__((always_inline)) {
         if (W85_ABL & 1) {
             buf[xlds] = xv[1] + xv[0];
@@ -185,52 +295,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
             buf[xlds + 2] = xv[3] + f32x4{xh[1], xh[2], xh[0], xh[7]};
             return;
         }
-        const int sel = pS * 2 + half;                      // wave-uniform
-        // (selected as integers so that they stay in scalar registers: a float ?: chain became a tree of branches)
-        auto pick = [&](unsigned v0, unsigned v1, unsigned v2, unsigned v3) __attribute__((always_inline)) {
-            return __builtin_bit_cast(float, sel == 0 ? v0 : (sel == 1 ? v1 : (sel == 2 ? v2 : v3)));
-        };
-        const float c2 = pick(0x3f800000u, 0x3e800000u, 0x40800000u, 0x40a80000u);        // 1.0 0.25 4.0 5.25
-        const float c4 = pick(0xc0880000u, 0xbfa00000u, 0xc0a00000u, 0xc0a80000u);        // -4.25 -1.25 -5.0 -5.25
-        const float c1 = pick(0x3f800000u, 0x3f000000u, 0x40000000u, 0xbf800000u);        // 1.0 0.5 2.0 -1.0
-        const float c3 = pick(0xc0880000u, 0xc0200000u, 0xc0200000u, 0x40a80000u);        // -4.25 -2.5 -2.5 5.25
-        const float c5 = pick(0x3f800000u, 0x40000000u, 0x3f000000u, 0xc0a80000u);        // 1.0 2.0 0.5 -5.25
-        const bool special = sel == 3;
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]), "+v"(xh[5]), "+v"(xh[6]), "+v"(xh[7]));
-        float Ea[6], Eb[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float d[8];
-#pragma unroll
-            for (int r = 1; r < 7; ++r)
-                d[r] = j == 0 ? dpp_shr1(xh[r], xv[r][3]) : (j == 5 ? dpp_shl1(xh[r], xv[r][0]) : xv[r][j - 1]);
-            float X = c2 * d[2] + (c4 * d[4] + d[6]);
-            float Y = c1 * d[1] + (c3 * d[3] + c5 * d[5]);
-            if (special) {                                  // (wave-uniform: pass B, waves 4-7 - the only user of rows 0 and 7)
-                d[0] = j == 0 ? dpp_shr1(xh[0], xv[0][3]) : (j == 5 ? dpp_shl1(xh[0], xv[0][0]) : xv[0][j - 1]);
-                d[7] = j == 0 ? dpp_shr1(xh[7], xv[7][3]) : (j == 5 ? dpp_shl1(xh[7], xv[7][0]) : xv[7][j - 1]);
-                X = X - d[0];
-                Y = Y + d[7];
-                Ea[j] = X;
-                Eb[j] = Y;
-            } else {
-                Ea[j] = X + Y;
-                Eb[j] = X - Y;
-            }
-        }
-        if (HAS_ISC) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                Ea[j] *= xsc;
-                Eb[j] *= xsc;
-            }
-        }
-        float Ua[6], Ub[6];
-        tt(Ea, Ua);
-        tt(Eb, Ub);
-        buf[xlds] = f32x4{Ua[0], Ua[1], Ua[2], Ua[3]};
-        buf[xlds + 1] = f32x4{Ua[4], Ua[5], Ub[0], Ub[1]};
-        buf[xlds + 2] = f32x4{Ub[2], Ub[3], Ub[4], Ub[5]};
+        f32x4 o0, o1, o2;
+        w85_transform<HAS_ISC>(xv, xh, pS * 2 + half, xsc, o0, o1, o2);      // (the selector is wave-uniform)
+        buf[xlds] = o0;
+        buf[xlds + 1] = o1;
+        buf[xlds + 2] = o2;
     };
     auto advance = [&](int& ps, int& ci0) __attribute__((always_inline)) {    // next super-slab, clamped at the last one
         int nc = ci0 + KS, np = ps;
@@ -357,19 +427,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
         if (cM >= g.CinP) {
             cM = 0;
             if (pM == 0) {
-                // pass boundary: carry the finished phases (p1, p2, p3, p4) into the accumulators of (p5, p6, p0, p7)
-                asm volatile("s_nop 15\n\ts_nop 15");
-#pragma unroll
-                for (int p = 0; p < 6; ++p)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float m1 = acc[0][p][e], m2 = acc[0][6 + p][e], m3 = acc[1][p][e], m4 = acc[1][6 + p][e];
-                        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-                        acc[0][p][e] = (2.f * s12 + d12) + (8.f * s34 + 2.f * d34);          // 3 m1 + m2 + 10 m3 + 6 m4
-                        acc[0][6 + p][e] = (2.f * s12 - d12) + (8.f * s34 - 2.f * d34);      // m1 + 3 m2 + 6 m3 + 10 m4
-                        acc[1][p][e] = -3.f * s12 - 15.f * s34;
-                        acc[1][6 + p][e] = 0.75f * d12 + 7.5f * d34;
-                    }
+                w85_carry(acc);
             }
             ++pM;
         }
@@ -380,33 +438,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
 #undef Y_WLOAD
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
 
-    // ---- output: rows r = 0..3 from (M5, M6, M0, M7) = acc[0][0..5], acc[0][6..11], acc[1][0..5], acc[1][6..11]
-    const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
-    const int t = t0 + 4 * l15;
-#pragma unroll
-    for (int row = 0; row < 4; ++row) {
-        const int f = fa + row * a.dil;
-        const bool pv = f < a.F && t < a.T;
-        const long sp = pv ? (long)f * a.T + t : 0;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int co = co0 + wave * 16 + 4 * lk + kk;
-            const float os = has_os ? a.oscale[b * a.Cout + co] : 1.f;
-            const f32x4 rr = (has_res && pv) ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)co * a.res_cs + sp)
-                                             : f32x4{0.f, 0.f, 0.f, 0.f};
-            float m[6];
-#pragma unroll
-            for (int tp = 0; tp < 6; ++tp) {
-                const float M5 = acc[0][tp][kk], M6 = acc[0][6 + tp][kk], M0 = acc[1][tp][kk], M7 = acc[1][6 + tp][kk];
-                m[tp] = row == 0 ? (M5 + M6) + M0 : (row == 1 ? 0.5f * (M5 - M6) : (row == 2 ? 0.25f * (M5 + M6) : 0.125f * (M5 - M6) + M7));
-            }
-            const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-            f32x4 y = {m[0] + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + m[5]};
-            const float sc = a.alpha * os;
-            y = y * sc + a.rbeta * rr;
-            if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
-        }
-    }
+    w85_epilogue(a, acc, b, co0 + wave * 16, fa, t0, lk, l15);
 #endif
 }
 
@@ -481,24 +513,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino85s_kernel(babe_conv_args a, 
                 xv[i][p][0] = xv[i][p][7] = f32x4{0.f, 0.f, 0.f, 0.f};
                 xsc[i][p] = 1.f;
             }
-        auto dpp_shr1 = [](float old, float src) __attribute__((always_inline)) {
-            asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
-            return old;
-        };
-        auto dpp_shl1 = [](float old, float src) __attribute__((always_inline)) {
-            asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
-            return old;
-        };
-        auto tt = [](const float (&E)[6], float (&U)[6]) {
-            const float e = E[4] - 4.f * E[2], o = E[3] - 4.f * E[1];
-            const float e2 = E[4] - E[2], o2 = E[3] - E[1];
-            U[0] = 4.f * E[0] + (E[4] - 5.f * E[2]);
-            U[1] = e + o;
-            U[2] = e - o;
-            U[3] = e2 + 2.f * o2;
-            U[4] = e2 - 2.f * o2;
-            U[5] = 4.f * E[1] + (E[5] - 5.f * E[3]);
-        };
         // the rows of super-slab (ps, ci0) into register set `st` (rows 0 and 7 in pass B only), its halo and input scale
         auto issue = [&](int st, int ps, int ci0) __attribute__((always_inline)) {
 #pragma unroll
@@ -527,50 +541,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino85s_kernel(babe_conv_args a, 
                 const int xl = (((vw0 + p) * 4 + s_ch) * NU + s_tu) * 6;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    const int sel = ps * 2 + hf;
-                    auto pick = [&](unsigned v0, unsigned v1, unsigned v2, unsigned v3) __attribute__((always_inline)) {
-                        return __builtin_bit_cast(float, sel == 0 ? v0 : (sel == 1 ? v1 : (sel == 2 ? v2 : v3)));
-                    };
-                    const float c2 = pick(0x3f800000u, 0x3e800000u, 0x40800000u, 0x40a80000u);        // 1.0 0.25 4.0 5.25
-                    const float c4 = pick(0xc0880000u, 0xbfa00000u, 0xc0a00000u, 0xc0a80000u);        // -4.25 -1.25 -5.0 -5.25
-                    const float c1 = pick(0x3f800000u, 0x3f000000u, 0x40000000u, 0xbf800000u);        // 1.0 0.5 2.0 -1.0
-                    const float c3 = pick(0xc0880000u, 0xc0200000u, 0xc0200000u, 0x40a80000u);        // -4.25 -2.5 -2.5 5.25
-                    const float c5 = pick(0x3f800000u, 0x40000000u, 0x3f000000u, 0xc0a80000u);        // 1.0 2.0 0.5 -5.25
-                    const bool special = sel == 3;
-                    float Ea[6], Eb[6];
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        float d[8];
-#pragma unroll
-                        for (int r = 1; r < 7; ++r)
-                            d[r] = j == 0 ? dpp_shr1(xh[r], xv[st][p][r][3]) : (j == 5 ? dpp_shl1(xh[r], xv[st][p][r][0]) : xv[st][p][r][j - 1]);
-                        float X = c2 * d[2] + (c4 * d[4] + d[6]);
-                        float Y = c1 * d[1] + (c3 * d[3] + c5 * d[5]);
-                        if (special) {
-                            d[0] = j == 0 ? dpp_shr1(xh[0], xv[st][p][0][3]) : (j == 5 ? dpp_shl1(xh[0], xv[st][p][0][0]) : xv[st][p][0][j - 1]);
-                            d[7] = j == 0 ? dpp_shr1(xh[7], xv[st][p][7][3]) : (j == 5 ? dpp_shl1(xh[7], xv[st][p][7][0]) : xv[st][p][7][j - 1]);
-                            X = X - d[0];
-                            Y = Y + d[7];
-                            Ea[j] = X;
-                            Eb[j] = Y;
-                        } else {
-                            Ea[j] = X + Y;
-                            Eb[j] = X - Y;
-                        }
-                    }
-                    if (HAS_ISC) {
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) {
-                            Ea[j] *= xsc[st][p];
-                            Eb[j] *= xsc[st][p];
-                        }
-                    }
-                    float Ua[6], Ub[6];
-                    tt(Ea, Ua);
-                    tt(Eb, Ub);
-                    buf[xl + hf * 3] = f32x4{Ua[0], Ua[1], Ua[2], Ua[3]};
-                    buf[xl + hf * 3 + 1] = f32x4{Ua[4], Ua[5], Ub[0], Ub[1]};
-                    buf[xl + hf * 3 + 2] = f32x4{Ub[2], Ub[3], Ub[4], Ub[5]};
+                    f32x4 o0, o1, o2;
+                    w85_transform<HAS_ISC>(xv[st][p], xh, ps * 2 + hf, xsc[st][p], o0, o1, o2);
+                    buf[xl + hf * 3] = o0;
+                    buf[xl + hf * 3 + 1] = o1;
+                    buf[xl + hf * 3 + 2] = o2;
                 }
             }
         };
@@ -675,20 +650,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85s_kernel(babe_conv_args a, 
         cM += KS;
         if (cM >= g.CinP) {
             cM = 0;
-            if (pM == 0) {
-                asm volatile("s_nop 15\n\ts_nop 15");
-#pragma unroll
-                for (int p = 0; p < 6; ++p)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float m1 = acc[0][p][e], m2 = acc[0][6 + p][e], m3 = acc[1][p][e], m4 = acc[1][6 + p][e];
-                        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-                        acc[0][p][e] = (2.f * s12 + d12) + (8.f * s34 + 2.f * d34);
-                        acc[0][6 + p][e] = (2.f * s12 - d12) + (8.f * s34 - 2.f * d34);
-                        acc[1][p][e] = -3.f * s12 - 15.f * s34;
-                        acc[1][6 + p][e] = 0.75f * d12 + 7.5f * d34;
-                    }
-            }
+            if (pM == 0) w85_carry(acc);
             ++pM;
         }
     }
@@ -698,32 +660,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85s_kernel(babe_conv_args a, 
 #undef Z_WLOAD
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
 
-    const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
-    const int t = t0 + 4 * l15;
-#pragma unroll
-    for (int row = 0; row < 4; ++row) {
-        const int f = fa + row * a.dil;
-        const bool pv = f < a.F && t < a.T;
-        const long sp = pv ? (long)f * a.T + t : 0;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int co = co0 + wave * 16 + 4 * lk + kk;
-            const float os = has_os ? a.oscale[b * a.Cout + co] : 1.f;
-            const f32x4 rr = (has_res && pv) ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)co * a.res_cs + sp)
-                                             : f32x4{0.f, 0.f, 0.f, 0.f};
-            float m[6];
-#pragma unroll
-            for (int tp = 0; tp < 6; ++tp) {
-                const float M5 = acc[0][tp][kk], M6 = acc[0][6 + tp][kk], M0 = acc[1][tp][kk], M7 = acc[1][6 + tp][kk];
-                m[tp] = row == 0 ? (M5 + M6) + M0 : (row == 1 ? 0.5f * (M5 - M6) : (row == 2 ? 0.25f * (M5 + M6) : 0.125f * (M5 - M6) + M7));
-            }
-            const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-            f32x4 y = {m[0] + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + m[5]};
-            const float sc = a.alpha * os;
-            y = y * sc + a.rbeta * rr;
-            if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
-        }
-    }
+    w85_epilogue(a, acc, b, co0 + wave * 16, fa, t0, lk, l15);
 #endif
 }
 

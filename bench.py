@@ -172,7 +172,7 @@ PMC_TRAFFIC_FILE = "r05_conv_traffic.json"
 
 
 def conv_traffic(precision):
-    """HBM-side bytes per launch of the dominant conv kernel (conv_wino45x_kernel) from the committed PMC passes (rocprofv3 cannot run inside the bench; the
+    """HBM-side bytes per launch of the dominant conv kernel (conv_wino85_kernel / conv_wino85s_kernel) from the committed PMC passes (rocprofv3 cannot run inside the bench; the
     passes are separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this command, profiles/README.md)."""
     path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     if precision != "f32" or not os.path.exists(path):
@@ -201,7 +201,7 @@ def spawn_ranks(n):
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 HBM_SLOTS = ["conv11", "gn_stats", "scale_gelu", "gn_bwd_partial", "gn_bwd_apply", "resample", "axpby", "cqt_band_analysis",
              "cqt_band_synthesis", "cqt_gather", "stft_fwd", "istft", "mag_stats", "sampler"]
-CONV_SLOTS = ["conv53_wino45", "conv53_wino4", "conv53_wino2", "conv53_direct", "conv53_fewco", "conv11", "conv_bf16", "conv_bf16p"]
+CONV_SLOTS = ["conv53_wino85", "conv53_wino45", "conv53_wino4", "conv53_wino2", "conv53_direct", "conv53_fewco", "conv11", "conv_bf16", "conv_bf16p"]
 
 
 def slot_table(prof, names, wall_s=None):
@@ -362,8 +362,8 @@ def main():
                  "bf16": "bf16 (bf16 MFMA, fp32 storage+accumulate)"}[a.precision]
         peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "f32" else 2500.0
         dom = "conv53_wino4" if a.precision == "f32" else "conv_bf16"
-        if a.precision == "f32" and timed is not None and timed["conv53_wino45"]["ms"] > timed["conv53_wino4"]["ms"]:
-            dom = "conv53_wino45"                        # the nested-Winograd kernel takes most of the (5,3) layers
+        if a.precision == "f32" and timed is not None:
+            dom = max(("conv53_wino85", "conv53_wino45", "conv53_wino4"), key=lambda k: timed[k]["ms"])   # the (5,3) kernel with the most time
         if a.precision == "bf16" and timed is not None and timed["conv_bf16p"]["launches"]:
             dom = "conv_bf16p"                           # the pipelined kernel takes the (5,3) layers of the bf16 build
         if timed is not None and timed[dom]["launches"]:
@@ -376,7 +376,12 @@ def main():
             tr = conv_traffic(a.precision)
             roof = {
                 "bound": "mfma",
-                "kernel": (("conv_wino45x_kernel / conv_wino45_kernel (128- / 96- and 64-channel tiles of the same algorithm; one "
+                "kernel": (("conv_wino85_kernel / conv_wino85s_kernel (128- / 96- and 64-channel tiles of the same algorithm; one "
+                            "measurement slot): nested Winograd F(4,5) along frequency x F(4,3) along time, fp32 "
+                            "v_mfma_f32_16x16x4_f32 (executes 0.2 of the algorithmic flops), fwd + input-VJP launches of the "
+                            "(5,3) layers of the UNet with >= 64 channels whose row quads are >= 85 % full (all_conv_kernels "
+                            "has the rest)" if dom == "conv53_wino85" else
+                            "conv_wino45x_kernel / conv_wino45_kernel (128- / 96- and 64-channel tiles of the same algorithm; one "
                             "measurement slot): nested Winograd F(2,5) along frequency x F(4,3) along time, fp32 "
                             "v_mfma_f32_16x16x4_f32 (executes 0.3 of the algorithmic flops), fwd + input-VJP launches of every "
                             "(5,3) layer of the UNet with >= 64 channels (all_conv_kernels has the rest)" if dom == "conv53_wino45" else
@@ -388,8 +393,10 @@ def main():
                 "achieved": round(r["flops"] / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(r["exec_flops"] / sec / 1e12 / peak, 4),
                 "frac_definition": "EXECUTED MFMA flops / duration / peak (F(4,3) executes 1/2, the nested F(2,5)xF(4,3) "
-                                   "kernel 3/10 of the algorithmic direct-convolution flops that `achieved` counts); "
-                                   "algorithmic_frac = achieved / peak.  "
+                                   "kernel 3/10, the nested F(4,5)xF(4,3) kernel 2/10 of the algorithmic direct-convolution "
+                                   "flops that `achieved` counts: a kernel that executes FEWER flops for the same outputs is "
+                                   "faster at a LOWER frac - rounds 3-5 read 0.59-0.60 on the F(2,5) kernel at 310 algorithmic "
+                                   "TFLOP/s); algorithmic_frac = achieved / peak.  "
                                    "`achieved` / `frac` / `avg_launch_us` are the kernel ALONE on the GPU (the `serial` "
                                    "block: all batch items on one stream, what the rocprofv3 summary under profiles/ "
                                    "reproduces) when that block exists; the same launches inside the two-lane timed region, "

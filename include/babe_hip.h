@@ -170,9 +170,11 @@ int babe_resample_res(const float* in, long in_bs, long in_cs, const float* res,
 int babe_resample_sinc(const float* x, long x_bs, float* out, long out_bs, int B, long L_in, long L_out, const float* kernel,
                        const int* krange, int orig, int new_, int width, void* stream);
 
-/* ---- EXPERIMENTAL (round 5, not on the product path unless BABE_CONV_F45=1): nested Winograd F(4,5) x F(4,3) for the same (5,3)
- * convs as babe_conv2d_wino45 - 3.0 multiplies per output instead of 4.5 (csrc/conv_wino85.hip).  128-channel output tiles,
- * Cin % 16 == 0; weights [2 passes][Cin/4][2][4][Cout][12] from babe_conv_pack_weights_wino85. */
+/* ---- nested Winograd F(4,5) along frequency x F(4,3) along time for the same (5,3) convs as babe_conv2d_wino45 (Conv2d at
+ * networks/cqtdiff+.py:79-88, 433-436): 3.0 multiplies per output instead of 4.5 (csrc/conv_wino85.hip).  Output-channel tiles of
+ * 128, 96 or 64 (Cout a multiple of one of them), Cin % 16 == 0, one source; weights [2 passes][Cin/4][2][Cout/16][3][4][16][4] from
+ * babe_conv_pack_weights_wino85.  _preferred: the problem is supported AND its row quads x time tiles are >= 85 % full - what
+ * babe_conv2d_auto and babe_amd/ops.py::conv2d dispatch on (BABE_CONV_F45=0 in the Python host leaves everything to wino45). */
 long babe_conv_packed_size_wino85(int Cout, int Cin, int transpose_flip);
 int babe_conv_pack_weights_wino85(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip, void* stream);
 int babe_conv2d_wino85_supported(const babe_conv_args* a);
@@ -187,7 +189,7 @@ typedef struct {                       /* every image babe_amd/ops.py::PackedCon
     const void *fwd, *bwd;             /* babe_conv_pack_weights_nt (fp32) or babe_conv_pack_weights_bf16 images, transpose_flip 0 / 1 */
     const float *fwd_wino, *bwd_wino, *fwd_wino4, *bwd_wino4, *fwd_wino45, *bwd_wino45;
     const float* w_raw;                /* reference layout, for babe_conv2d_fewco (<= 4 channels on one side) */
-    const float *fwd_wino85, *bwd_wino85;  /* babe_conv_pack_weights_wino85 images (128-channel output tiles), or NULL */
+    const float *fwd_wino85, *bwd_wino85;  /* babe_conv_pack_weights_wino85 images, or NULL */
 } babe_packed_conv;
 /* conv with the kernel chosen by the library; a->w_packed, Cin, Cout, KH, KW are filled in from pc / transpose */
 int babe_conv2d_auto(babe_conv_args* a, const babe_packed_conv* pc, int transpose, void* stream);

@@ -724,6 +724,27 @@ def test_conv2d_nested_winograd_f45_vs_float64(ops, B, Cin, Cout, Fq, T, dil):
     assert e0 < 1e-5 and e1 < 1e-5 and e2 < 1e-5
 
 
+def test_f45_tile_widths_are_bit_identical(ops):
+    """conv_wino85_kernel (128-channel tiles, every wave transforms and multiplies) and conv_wino85s_kernel (96- / 64-channel tiles,
+    specialised waves) do the same arithmetic in the same order for a given output: a 128-channel conv on the first equals, bit for
+    bit, the same conv done as two 64-channel convs on the second; a 192-channel conv (two 96-channel tiles) equals three
+    64-channel convs."""
+    from babe_amd._lib import dispatch_counts
+    for Cout, Cin, Fq, T, dil in ((128, 128, 48, 128, 2), (192, 96, 32, 196, 1)):
+        g = torch.Generator().manual_seed(Cout + Cin)
+        x = torch.randn(2, Cin, Fq, T, generator=g).cuda()
+        w = (torch.randn(Cout, Cin, 5, 3, generator=g) / math.sqrt(Cin * 15)).cuda()
+        isc = torch.randn(2, Cin, generator=g).cuda()
+        out = torch.empty(2, Cout, Fq, T, device="cuda")
+        dispatch_counts(reset=True)
+        ops.conv2d(x, ops.PackedConv(w), out, dil=dil, in_scale=isc, force_f45=True)
+        parts = torch.empty_like(out)
+        for c0 in range(0, Cout, 64):
+            ops.conv2d(x, ops.PackedConv(w[c0:c0 + 64].contiguous()), parts[:, c0:c0 + 64], dil=dil, in_scale=isc, force_f45=True)
+        assert dispatch_counts()["conv53_wino85"] == 1 + Cout // 64
+        assert torch.equal(out, parts), float((out - parts).abs().max())
+
+
 def test_conv2d_f45_dispatch_rule_and_tile_order(ops):
     """Which launches take the F(4,5) x F(4,3) kernel by default: 128-channel output tiles whose row quads x time tiles are >= 85 %
     full (babe_conv2d_wino85_preferred); force_nested keeps the F(2,5) x F(4,3) kernel; two-source convs never take it.  The

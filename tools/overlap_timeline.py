@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench as BN                                        # noqa: E402  (synthetic clip, constants)
 
-FAMILIES = {"conv53_wino45": "conv53", "conv53_wino4": "conv53", "conv53_wino2": "conv53", "conv53_direct": "conv53",
+FAMILIES = {"conv53_wino85": "conv53", "conv53_wino45": "conv53", "conv53_wino4": "conv53", "conv53_wino2": "conv53", "conv53_direct": "conv53",
             "conv53_fewco": "conv_small", "conv11": "conv11", "conv_bf16": "conv53", "conv_bf16p": "conv53",
             "gn_stats": "gn_fwd", "scale_gelu": "gn_fwd", "gn_bwd_partial": "gn_vjp", "gn_bwd_apply": "gn_vjp",
             "resample": "ew", "axpby": "ew"}
