@@ -14,4 +14,13 @@ for (B, C, F, T) in [(1, 64, 64, 4096), (1, 128, 256, 512), (1, 256, 448, 64)]:
     for _ in range(50): f()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 50 * 1e3
-    print((B, C, F, T), f"gn_partial {us:.1f} us {x.numel()*4/us/1e3:.0f} GB/s")
+    da = torch.randn_like(x); sc = torch.rand(B, C, device="cuda") + 0.5
+    part2 = torch.empty(B * G * S, device="cuda", dtype=torch.float64)
+    f2 = lambda: check(lib().babe_gn_bwd_partial(ptr(x), ptr(da), ptr(sc), ptr(part2), B, C, G, F * T, S, stream()), "bp")
+    for _ in range(3): f2()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50): f2()
+    e1.record(); torch.cuda.synchronize()
+    us2 = e0.elapsed_time(e1) / 50 * 1e3
+    print((B, C, F, T), f"S={S}: gn_partial {us:.1f} us {x.numel()*4/us/1e3:.0f} GB/s | gn_bwd_partial {us2:.1f} us {x.numel()*8/us2/1e3:.0f} GB/s")
