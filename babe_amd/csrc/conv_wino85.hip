@@ -36,7 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef W85_ABL
 #define W85_ABL 0      // timing ablations only (tools/f45_ablate.py): 1 no transform arithmetic, 2 no row loads, 4 no weight loads,
-#endif                 // 8 no X reads, 16 no MFMA, 32 rows loaded by waves 0-3 only, 64 / 128 row loads that always hit L2 / L1 - results are wrong
+#endif                 // 8 no X reads, 16 no MFMA, 32 rows loaded by waves 0-3 only, 64 / 128 row loads that always hit L2 / L1, 512 no epilogue, 1024 no pass carry - results are wrong
 
 namespace {
 
@@ -157,6 +157,11 @@ __device__ __forceinline__ void w85_epilogue(const babe_conv_args& a, const f32x
             const f32x4 rr = (has_res && pv) ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)co * a.res_cs + sp)
                                              : f32x4{0.f, 0.f, 0.f, 0.f};
             float m[6];
+            if (W85_ABL & 4096) {                       // (no output transform: raw accumulators stored)
+                const f32x4 y = {acc[0][row][kk], acc[0][6 + row][kk], acc[1][row][kk], acc[1][6 + row][kk]};
+                if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
+                continue;
+            }
 #pragma unroll
             for (int tp = 0; tp < 6; ++tp) {
                 const float M5 = acc[0][tp][kk], M6 = acc[0][6 + tp][kk], M0 = acc[1][tp][kk], M7 = acc[1][6 + tp][kk];
@@ -171,7 +176,9 @@ __device__ __forceinline__ void w85_epilogue(const babe_conv_args& a, const f32x
             y[1] = __builtin_fmaf(y1, sc, a.rbeta * rr[1]);
             y[2] = __builtin_fmaf(y2, sc, a.rbeta * rr[2]);
             y[3] = __builtin_fmaf(y3, sc, a.rbeta * rr[3]);
-            if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
+            if (W85_ABL & 2048) {                       // (no stores: the arithmetic stays)
+                if (y[0] == 12345.f && y[1] == 5.f) *reinterpret_cast<f32x4*>(a.out) = y;
+            } else if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
         }
     }
 }
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
         cM += KS;
         if (cM >= g.CinP) {
             cM = 0;
-            if (pM == 0) {
+            if (pM == 0 && !(W85_ABL & 1024)) {
                 w85_carry(acc);
             }
             ++pM;
@@ -438,6 +445,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
 #undef Y_WLOAD
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
 
+    if (W85_ABL & 512) {                                 // (no output transform: one store keeps the accumulators alive)
+        f32x4 sacc = acc[0][0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 12; ++p) sacc += acc[i][p];
+        if (sacc[0] == 12345.f) *reinterpret_cast<f32x4*>(a.out) = sacc;
+        return;
+    }
     w85_epilogue(a, acc, b, co0 + wave * 16, fa, t0, lk, l15);
 #endif
 }
