@@ -724,6 +724,52 @@ def test_conv2d_nested_winograd_f45_vs_float64(ops, B, Cin, Cout, Fq, T, dil):
     assert e0 < 1e-5 and e1 < 1e-5 and e2 < 1e-5
 
 
+def test_conv2d_f45_random_shapes_vs_float64(ops):
+    """Twelve seeded random problems across the kernel's supported domain - Cin 16 .. 272 in steps of 16, Cout from the three tile
+    widths and their multiples, 5 .. 70 rows, T a multiple of 4 from 64, dilation 1 .. 9, B 1 .. 3, with and without the fused
+    epilogue / input scale - forward and (where the transposed problem is supported) input-VJP against the float64 direct conv."""
+    import random
+    from babe_amd._lib import dispatch_counts
+    rnd = random.Random(4543)
+    for case in range(12):
+        Cin = 16 * rnd.randint(1, 17)
+        Cout = rnd.choice([64, 96, 128, 192, 256, 320])
+        Fq, T, dil, B = rnd.randint(5, 70), 4 * rnd.randint(16, 50), rnd.randint(1, 9), rnd.randint(1, 3)
+        g = torch.Generator().manual_seed(case)
+        x = torch.randn(B, Cin, Fq, T, generator=g)
+        w = torch.randn(Cout, Cin, 5, 3, generator=g) / math.sqrt(Cin * 15)
+        ref = UN.conv_same(x.double(), w.double(), dil)
+        pc = ops.PackedConv(w.cuda())
+        out = torch.empty(B, Cout, Fq, T, device="cuda")
+        fused = case % 2 == 1
+        res = torch.randn(B, Cout, Fq, T, generator=g)
+        osc = torch.randn(B, Cout, generator=g)
+        dispatch_counts(reset=True)
+        if fused:
+            out.copy_(res)
+            ops.conv2d(x.cuda(), pc, out, dil=dil, res=out, oscale=osc.cuda(), alpha=1.3, rbeta=-0.4, force_f45=True)
+            ref = 1.3 * ref * osc[:, :, None, None].double() - 0.4 * res.double()
+        else:
+            ops.conv2d(x.cuda(), pc, out, dil=dil, force_f45=True)
+        assert dispatch_counts()["conv53_wino85"] == 1
+        e0 = rel(out, ref)
+        e1 = float("nan")
+        if pc.bwd_wino85 is not None:
+            gy = torch.randn(B, Cout, Fq, T, generator=g)
+            isc = torch.randn(B, Cout, generator=g) if fused else None
+            xr = x.double().requires_grad_(True)
+            y = UN.conv_same(xr, w.double(), dil)
+            gsrc = gy.double() * isc[:, :, None, None].double() if fused else gy.double()
+            gref, = torch.autograd.grad((y * gsrc).sum(), xr)
+            gx = torch.empty(B, Cin, Fq, T, device="cuda")
+            dispatch_counts(reset=True)
+            ops.conv2d(gy.cuda(), pc, gx, dil=dil, transpose=True, in_scale=isc.cuda() if fused else None, force_f45=True)
+            assert dispatch_counts()["conv53_wino85"] == 1
+            e1 = rel(gx, gref)
+        print(f"case {case}: B={B} Cin={Cin} Cout={Cout} F={Fq} T={T} dil={dil} fused={fused}: fwd {e0:.2e} vjp {e1:.2e}")
+        assert e0 < 1e-5 and not (e1 > 1e-5)
+
+
 def test_f45_tile_widths_are_bit_identical(ops):
     """conv_wino85_kernel (128-channel tiles, every wave transforms and multiplies) and conv_wino85s_kernel (96- / 64-channel tiles,
     specialised waves) do the same arithmetic in the same order for a given output: a 128-channel conv on the first equals, bit for
