@@ -34,6 +34,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef W85_RD
+#define W85_RD 12      // weight register ring: groups in flight (a multiple of 3 that divides 24)
+#endif
 #ifndef W85_ABL
 #define W85_ABL 0      // timing ablations only (tools/f45_ablate.py): 1 no transform arithmetic, 2 no row loads, 4 no weight loads,
 #endif                 // 8 no X reads, 16 no MFMA, 32 rows loaded by waves 0-3 only, 64 / 128 row loads that always hit L2 / L1, 512 no epilogue, 1024 no pass carry - results are wrong
@@ -188,9 +191,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
 #if __HIP_DEVICE_COMPILE__
     constexpr int KS = 16, KQ = 4, NU = 16, BN = 128;
     constexpr int XSZ = KS * NU * 6;                    // float4 per activation super-slab (16 ci x 16 units x 24 floats)
-#ifndef W85_RD
-#define W85_RD 12
-#endif
     constexpr int RD = W85_RD;                          // weight register ring: groups in flight (a multiple of 3 that divides 24)
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     f32x4* smem = reinterpret_cast<f32x4*>(smem_f);
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
 template <bool HAS_ISC, int NW>
 __global__ __launch_bounds__(512, 1) void conv_wino85s_kernel(babe_conv_args a, Wino85Geom g, const float* __restrict__ wq) {
 #if __HIP_DEVICE_COMPILE__
-    constexpr int KS = 16, KQ = 4, NU = 16, BN = 16 * NW, RD = 12;
+    constexpr int KS = 16, KQ = 4, NU = 16, BN = 16 * NW, RD = W85_RD;
     constexpr int TW = 8 - NW, PPL = 4 / TW;            // transform waves; channel quads per transform wave
     static_assert(NW == 6 || NW == 4, "tile width");
     constexpr int XSZ = KS * NU * 6;
