@@ -396,13 +396,15 @@ def main():
                                    "kernel 3/10, the nested F(4,5)xF(4,3) kernel 2/10 of the algorithmic direct-convolution "
                                    "flops that `achieved` counts: a kernel that executes FEWER flops for the same outputs is "
                                    "faster at a LOWER frac - rounds 3-5 read 0.59-0.60 on the F(2,5) kernel at 310 algorithmic "
-                                   "TFLOP/s); algorithmic_frac = achieved / peak.  "
+                                   "TFLOP/s; frac_if_executing_3_10 = what this launch rate would read on that kernel's flop "
+                                   "count, for comparison across rounds only); algorithmic_frac = achieved / peak.  "
                                    "`achieved` / `frac` / `avg_launch_us` are the kernel ALONE on the GPU (the `serial` "
                                    "block: all batch items on one stream, what the rocprofv3 summary under profiles/ "
                                    "reproduces) when that block exists; the same launches inside the two-lane timed region, "
                                    "whose durations include the other lane's kernels, are under `timed_region`",
                 "algorithmic_frac": round(r["flops"] / sec / 1e12 / peak, 4),
                 "executed_tflops": round(r["exec_flops"] / sec / 1e12, 2),
+                "frac_if_executing_3_10": (round(0.3 * r["flops"] / sec / 1e12 / peak, 4) if dom == "conv53_wino85" else None),
                 "traffic": (tr or {}).get("bytes_per_launch"), "traffic_detail": tr,
                 "algorithmic_MB_per_launch": round(r["bytes"] / r["launches"] / 1e6, 2),
                 "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
@@ -432,6 +434,8 @@ def main():
                 roof["timed_region"] = {k: roof[k] for k in ("achieved", "frac", "algorithmic_frac", "executed_tflops",
                                                              "avg_launch_us", "launches")}
                 sr = roof["serial"]
+                if dom == "conv53_wino85":               # the same outputs per second on the round-4 algorithm (3/10 executed) would read this frac
+                    roof["frac_if_executing_3_10"] = round(0.3 * q["flops"] / qs / 1e12 / peak, 4)
                 roof.update(achieved=sr["achieved"], frac=sr["frac"], algorithmic_frac=sr["algorithmic_frac"],
                             executed_tflops=round(q["exec_flops"] / qs / 1e12, 2), avg_launch_us=sr["avg_launch_us"])
             hbm = {"peak_GB_per_s": HBM_PEAK_GBS, "bytes": "ALGORITHMIC bytes per launch (each operand touched once), DESIGN.md 3",

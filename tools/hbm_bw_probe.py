@@ -11,4 +11,4 @@ for mb in (64, 256, 1024, 4096):
     n = mb * 1024 * 1024 // 4
     x = torch.empty(n, device="cuda"); y = torch.empty(n, device="cuda")
     w = t(lambda: x.fill_(1.0)); r = t(lambda: x.sum()); c = t(lambda: y.copy_(x))
-    print(f"{mb:5d} MB: write {mb/1024/w/1.024:6.2f} TB/s | read {mb/1024/r/1.024:6.2f} TB/s | copy (r+w) {2*mb/1024/c/1.024:6.2f} TB/s")
+    print(f"{mb:5d} MB: write {mb*1.048576e-3/w:7.0f} GB/s | read {mb*1.048576e-3/r:7.0f} GB/s | copy (r+w) {2*mb*1.048576e-3/c:7.0f} GB/s")
