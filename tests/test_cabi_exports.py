@@ -94,3 +94,42 @@ def test_unet_plan_create_validates_every_block():
         mutate(d)
         ok, msg = create(d)
         assert not ok and "bad descriptor" in msg, (name, ok, msg)
+
+
+def test_f45_dispatch_rule_is_host_logic():
+    """babe_conv2d_wino85_supported / _preferred are pure host functions (no launch, no device pointer dereferenced): the dispatch
+    rule of the F(4,5) x F(4,3) kernels - output channels a multiple of 128 / 96 / 64, Cin % 16 == 0, one source, T % 4 == 0 and
+    >= 64, 16-byte aligned views; preferred = supported and row quads x time tiles >= 85 % full - checked without a GPU."""
+    import ctypes as C
+    from babe_amd._lib import ConvArgs, lib
+    L = lib()
+
+    def args(Cin=128, Cout=128, F=64, T=128, dil=4, in2=None, in_=0x10000, B=1):
+        a = ConvArgs()
+        a.in_, a.in_bs, a.in_cs = in_, Cin * F * T, F * T
+        a.in2, a.in2_bs, a.in2_cs, a.cin_split = in2, 0, 0, Cin
+        a.out, a.out_bs, a.out_cs = 0x20000, Cout * F * T, F * T
+        a.res, a.res_bs, a.res_cs = None, 0, 0
+        a.in_scale = a.oscale = None
+        a.alpha, a.rbeta = 1.0, 0.0
+        a.B, a.Cin, a.Cout, a.F, a.T, a.KH, a.KW, a.dil = B, Cin, Cout, F, T, 5, 3, dil
+        return a
+
+    sup = lambda **k: L.babe_conv2d_wino85_supported(C.byref(args(**k)))
+    pre = lambda **k: L.babe_conv2d_wino85_preferred(C.byref(args(**k)))
+    for co in (64, 96, 128, 192, 256, 320, 384):
+        assert sup(Cout=co) == 1, co
+    for co in (16, 32, 48, 80, 112, 144):
+        assert sup(Cout=co) == 0, co
+    assert sup(Cin=16) == 1 and sup(Cin=24) == 0 and sup(Cin=8) == 0
+    assert sup(T=64) == 1 and sup(T=60) == 0 and sup(T=66) == 0 and sup(T=68) == 1
+    assert sup(in2=0x30000) == 0 and sup(in_=0x10004) == 0
+    a = args()
+    a.KH = 3
+    assert L.babe_conv2d_wino85_supported(C.byref(a)) == 0
+    # fill = F / (4 * quads * dil) * T / (64 * tiles): 16 rows per class = 4 full quads; 5 rows -> 2 quads = 0.625; 6 -> 0.75; 7 -> 0.875
+    assert pre(F=64, dil=4) == 1 and pre(F=40, dil=8) == 0 and pre(F=48, dil=8) == 0 and pre(F=56, dil=8) == 1
+    assert pre(F=64, dil=4, T=68) == 0 and pre(F=64, dil=4, T=120) == 1          # 68 of 128 steps / 120 of 128
+    # the benchmark's geometries that stay on the F(2,5) x F(4,3) kernel: 320 rows at dilation 32 (0.83), 384 rows at dilation 64 (0.75)
+    assert pre(F=320, T=256, dil=32) == 0 and pre(F=384, T=128, dil=64, Cin=256, Cout=256) == 0
+    assert pre(F=448, T=64, dil=64, Cin=256, Cout=256) == 1 and pre(F=320, T=256, dil=16) == 1
