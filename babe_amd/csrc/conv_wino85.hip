@@ -20,8 +20,9 @@
 // coalesced 1 KB load per wave and group, 12 groups ahead); LDS holds only the transformed activations (2 x 24 KB).  The first build
 // of this kernel staged the weights through a wave-private LDS-DMA ring like conv_wino45x_kernel: its ablations (tools/f45_ablate.py,
 // profiles/r05_f45_ablate.txt) charged 20 % of the time to the DMA and 18 % to the operand reads - LDS bandwidth was the limit.
-// Transform (128-channel kernel): thread = (ci, unit, half): waves 0-3 compute the first phase pair of the pass, waves 4-7 the second,
-// for 4 input channels x 16 units each - coefficients are wave-uniform.
+// Transform (128-channel kernel): thread = (ci, unit) in waves 0-3 (wave w and w + 4 share a SIMD): they load the rows once and compute
+// both phase pairs of the pass, coefficients wave-uniform; waves 4-7 only multiply (W85_HALFLOAD; the first form - every wave one
+// pair from its own copy of the rows - is the 0 setting).
 // 96- and 64-channel tiles: conv_wino85s_kernel below - waves 0 .. NW-1 only multiply, waves NW .. 7 only load and transform, which
 // balances the four SIMDs where six (four) multiplying waves alone cannot.  All three produce the same sums in the same order for a
 // given (co, output): a conv run as 64-channel tiles equals the same conv run as one 128-channel tile bit for bit.
@@ -34,6 +35,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef W85_HALFLOAD
+#define W85_HALFLOAD 1 // in the 128-channel kernel waves 0-3 load the rows and transform BOTH phase pairs of their (ci, unit), waves 4-7
+#endif                 // only multiply (0: every wave loads and transforms one pair - twice the row loads; -0.6 % on the whole job)
 #ifndef W85_RD
 #define W85_RD 12      // weight register ring: groups in flight (a multiple of 3 that divides 24)
 #endif
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     // wait for two older operations more, which landed long ago.
     auto issue_rows = [&](int ps, int ci0, int r0, int r1) __attribute__((always_inline)) {
         const int so = (W85_ABL & (64 | 128)) ? 0 : (ci0 + 4 * wq4) * cs1 * 4;       // (64: always the first 4 channels: L2 hits)
-        if ((W85_ABL & 2) || ((W85_ABL & 32) && half)) return;
+        if ((W85_ABL & 2) || ((W85_ABL & 32) && half) || (W85_HALFLOAD && half)) return;
 #pragma unroll
         for (int r = 1; r < 7; ++r) {
             if (r < r0 || r >= r1) continue;
@@ -284,13 +288,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     };
     auto issue_halo = [&](int ci0) __attribute__((always_inline)) {
         const int so = (ci0 + 4 * wq4) * cs1 * 4;
-        if ((W85_ABL & 2) || ((W85_ABL & 32) && half)) return;
+        if ((W85_ABL & 2) || ((W85_ABL & 32) && half) || (W85_HALFLOAD && half)) return;
         xhl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ehalo, so, 0));
     };
     auto issue_isc = [&](int ci0) __attribute__((always_inline)) {
+        if (W85_HALFLOAD && half) return;
         if (HAS_ISC) xsc = a.in_scale[(long)b * a.Cin + ci0 + 4 * wq4 + s_ch];
     };
     auto halo_permute = [&]() __attribute__((always_inline)) {
+        if (W85_HALFLOAD && half) return;
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(xh[r]) : "v"(hsrc), "v"(xhl), "n"(32 * r));
@@ -300,6 +306,19 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
             buf[xlds] = xv[1] + xv[0];
             buf[xlds + 1] = xv[2] + xv[7];
             buf[xlds + 2] = xv[3] + f32x4{xh[1], xh[2], xh[0], xh[7]};
+            return;
+        }
+        if (W85_HALFLOAD) {                                  // waves 0-3: both phase pairs of their (ci, unit) from one set of rows
+            if (half) return;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]), "+v"(xh[5]), "+v"(xh[6]), "+v"(xh[7]));
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 o0, o1, o2;
+                w85_transform<HAS_ISC>(xv, xh, pS * 2 + hf, xsc, o0, o1, o2);
+                buf[xlds + 3 * hf] = o0;
+                buf[xlds + 3 * hf + 1] = o1;
+                buf[xlds + 3 * hf + 2] = o2;
+            }
             return;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]), "+v"(xh[5]), "+v"(xh[6]), "+v"(xh[7]));
