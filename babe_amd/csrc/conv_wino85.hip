@@ -808,7 +808,8 @@ static double wino85_fill(const babe_conv_args& a) {
 
 extern "C" int babe_conv2d_wino85_preferred(const babe_conv_args* ap) {
     if (!babe_conv2d_wino85_supported(ap)) return 0;
-    return wino85_fill(*ap) >= 0.85 ? 1 : 0;
+    static const double min_fill = [] { const char* e = getenv("BABE_W85_FILL"); return e ? atof(e) : 0.80; }();
+    return wino85_fill(*ap) >= min_fill ? 1 : 0;
 }
 
 extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino85, void* stream) {

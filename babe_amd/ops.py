@@ -29,7 +29,7 @@ WINOGRAD4 = _W not in ("0", "2", "1")
 # nested Winograd F(2,5) x F(4,3) (csrc/conv_wino45.hip) for the (5,3) layers it supports; BABE_CONV_WINO45=0 switches it off
 WINOGRAD45 = WINOGRAD4 and os.environ.get("BABE_CONV_WINO45", "1") != "0"
 # nested Winograd F(4,5) x F(4,3) (csrc/conv_wino85.hip) for the (5,3) layers with 128-channel output tiles whose row quads are
-# at least 85 % full (babe_conv2d_wino85_preferred); BABE_CONV_F45=0 leaves them to the F(2,5) x F(4,3) kernel
+# at least 80 % full (babe_conv2d_wino85_preferred); BABE_CONV_F45=0 leaves them to the F(2,5) x F(4,3) kernel
 WINOGRAD85 = WINOGRAD45 and os.environ.get("BABE_CONV_F45", "1") != "0"
 
 

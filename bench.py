@@ -379,7 +379,7 @@ def main():
                 "kernel": (("conv_wino85_kernel / conv_wino85s_kernel (128- / 96- and 64-channel tiles of the same algorithm; one "
                             "measurement slot): nested Winograd F(4,5) along frequency x F(4,3) along time, fp32 "
                             "v_mfma_f32_16x16x4_f32 (executes 0.2 of the algorithmic flops), fwd + input-VJP launches of the "
-                            "(5,3) layers of the UNet with >= 64 channels whose row quads are >= 85 % full (all_conv_kernels "
+                            "(5,3) layers of the UNet with >= 64 channels whose row quads are >= 80 % full (all_conv_kernels "
                             "has the rest)" if dom == "conv53_wino85" else
                             "conv_wino45x_kernel / conv_wino45_kernel (128- / 96- and 64-channel tiles of the same algorithm; one "
                             "measurement slot): nested Winograd F(2,5) along frequency x F(4,3) along time, fp32 "

@@ -173,7 +173,7 @@ int babe_resample_sinc(const float* x, long x_bs, float* out, long out_bs, int B
 /* ---- nested Winograd F(4,5) along frequency x F(4,3) along time for the same (5,3) convs as babe_conv2d_wino45 (Conv2d at
  * networks/cqtdiff+.py:79-88, 433-436): 3.0 multiplies per output instead of 4.5 (csrc/conv_wino85.hip).  Output-channel tiles of
  * 128, 96 or 64 (Cout a multiple of one of them), Cin % 16 == 0, one source; weights [2 passes][Cin/4][2][Cout/16][3][4][16][4] from
- * babe_conv_pack_weights_wino85.  _preferred: the problem is supported AND its row quads x time tiles are >= 85 % full - what
+ * babe_conv_pack_weights_wino85.  _preferred: the problem is supported AND its row quads x time tiles are >= 80 % full - what
  * babe_conv2d_auto and babe_amd/ops.py::conv2d dispatch on (BABE_CONV_F45=0 in the Python host leaves everything to wino45). */
 long babe_conv_packed_size_wino85(int Cout, int Cin, int transpose_flip);
 int babe_conv_pack_weights_wino85(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int transpose_flip, void* stream);

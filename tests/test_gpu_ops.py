@@ -792,7 +792,7 @@ def test_f45_tile_widths_are_bit_identical(ops):
 
 
 def test_conv2d_f45_dispatch_rule_and_tile_order(ops):
-    """Which launches take the F(4,5) x F(4,3) kernel by default: 128-channel output tiles whose row quads x time tiles are >= 85 %
+    """Which launches take the F(4,5) x F(4,3) kernel by default: 128-channel output tiles whose row quads x time tiles are >= 80 %
     full (babe_conv2d_wino85_preferred); force_nested keeps the F(2,5) x F(4,3) kernel; two-source convs never take it.  The
     XCD-contiguous tile order only renumbers the workgroups: results are bit-identical for every batch item."""
     from babe_amd._lib import dispatch_counts

@@ -84,7 +84,7 @@ def test_full_width_L368368_vs_reference_golden_all_wino4():
     # forward: 75 dilated ResnetBlock convs + 7 pyramid projections, all on the Winograd kernels: the nested
     # F(2,5) x F(4,3) kernel where its tiles are full (64 / 128 / 256 channels), conv_wino4p elsewhere (96 channels, the
     # 2-channel pyramid inputs, the high dilations of the 320- and 384-bin levels)
-    # (round 5: the 128- and 256-channel layers whose row quads are at least 85 % full take the F(4,5) x F(4,3) kernel)
+    # (round 5: the 128- and 256-channel layers whose row quads are at least 80 % full take the F(4,5) x F(4,3) kernel)
     assert cf["conv53_wino4"] + cf["conv53_wino45"] + cf["conv53_wino85"] == 82 and cf["conv53_wino45"] + cf["conv53_wino85"] >= 40, cf
     assert cf["conv53_wino85"] >= 25 and cb["conv53_wino85"] >= 25, (cf, cb)
     assert cf["conv53_wino2"] == 0 and cf["conv53_direct"] == 0, cf
