@@ -33,6 +33,12 @@ WINOGRAD45 = WINOGRAD4 and os.environ.get("BABE_CONV_WINO45", "1") != "0"
 WINOGRAD85 = WINOGRAD45 and os.environ.get("BABE_CONV_F45", "1") != "0"
 
 
+# (1,1) convs: 64-channel output tiles per workgroup (two 32-row tiles) wherever both directions' tile counts are even, instead of
+# the library default of up to 128: more workgroups on the small planes of the deep levels, where a launch has a few hundred
+# (whole-job A/B, same box: 2.431 / 2.432 vs 2.423 / 2.424 audio-sec/s; one tile: 2.399 / 2.395).  0 = library default.
+_C11_NT = int(os.environ.get("BABE_CONV11_NT", "2"))
+
+
 class PackedConv:
     """Conv2d weights packed for babe_conv2d, forward and input-VJP (flipped/transposed) versions.
     precision: 'f32' (exact fp32 MFMA), 'bf16' or 'bf16x3' (bf16 MFMA, see csrc/conv_bf16.hip)."""
@@ -41,6 +47,9 @@ class PackedConv:
         """nt: row tiles (x32 output channels) per workgroup of the direct kernel, 0 = default (include/babe_hip.h)."""
         self.precision = precision
         self.nt = nt
+        if nt == 0 and _C11_NT and w.shape[2] * w.shape[3] == 1 and ((w.shape[0] + 31) // 32) % _C11_NT == 0 \
+                and ((w.shape[1] + 31) // 32) % _C11_NT == 0:
+            self.nt = _C11_NT
         self.splits = PRECISIONS[precision]
         # Shapes that gain nothing from bf16 MFMA run on the fp32 kernels whatever the requested precision (exact AND at
         # least as fast): convs with <= 4 channels on one side (few-channel kernels), (1,1) kernels with fewer than 32
