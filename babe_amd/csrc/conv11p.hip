@@ -345,8 +345,11 @@ int babe_conv11p_launch(const babe_conv_args& a, int nt, hipStream_t s) {
     const long cot = g.CoutP / (nt * 32);
     const long b128 = (((long)a.F * a.T + 127) / 128) * cot * a.B, b256 = (((long)a.F * a.T + 255) / 256) * cot * a.B;
     const long cost1 = ((b128 + 767) / 768) * 3, cost2 = ((b256 + 511) / 512) * 4;
+    // Round 5: on the two-lane job the 128-position tiles win everywhere (2.441 / 2.440 vs 2.434 / 2.430 audio-sec/s with this cost
+    // model, 2.424 / 2.422 with 256-position tiles everywhere; profiles/r05_f45_ablate.txt): the model prices a launch ALONE on the
+    // GPU, and beside the other lane's kernels the smaller workgroups fill better.  BABE_CONV11P_NPW=2 / =a (the model) for A/B.
     static const char* ov = getenv("BABE_CONV11P_NPW");
-    const bool big = ov ? ov[0] == '2' : cost2 < cost1;
+    const bool big = ov ? (ov[0] == '2' || (ov[0] == 'a' && cost2 < cost1)) : false;
     switch (nt * 2 + (big ? 1 : 0)) {
         case 9: launch11<4, 2>(a, g, s); break;
         case 8: launch11<4, 1>(a, g, s); break;
