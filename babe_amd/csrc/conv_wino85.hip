@@ -271,8 +271,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
     float xh[8];
     int pS = 0;
     // the patch rows of super-slab (ps, ci0): rows 1..6 always, rows 0 and 7 in pass B only (a wave-uniform branch; pass A's phases
-    // +-1, +-2 do not touch them).  The counted waits below assume the SIX-row form - with the two extra loads of pass B they just
-    // wait for two older operations more, which landed long ago.
+    // +-1, +-2 do not touch them).  (hipcc counts the vmcnt of every wait from the loads it sees: nothing here is hand-counted.)
     auto issue_rows = [&](int ps, int ci0, int r0, int r1) __attribute__((always_inline)) {
         const int so = (W85_ABL & (64 | 128)) ? 0 : (ci0 + 4 * wq4) * cs1 * 4;       // (64: always the first 4 channels: L2 hits)
         if ((W85_ABL & 2) || ((W85_ABL & 32) && half) || (W85_HALFLOAD && half)) return;
