@@ -13,6 +13,31 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def rank_table(n_clips, world, n_devices=None):
+    """The static plan of a sharded job as rows (rank, device index, first clip, one-past-last clip): what `bench.py --gpus N
+    --dry-run` prints and what restore_clips_sharded executes (rank r restores clips [lo, hi) on device r mod n_devices)."""
+    nd = n_devices or world
+    return [(r, r % max(nd, 1)) + shard_range(n_clips, r, world) for r in range(world)]
+
+
+def pin_host_threads(local_rank, local_world, cpus=None):
+    """Give each rank of a node its own contiguous block of the host's CPUs (os.sched_setaffinity, in-process, BEFORE the first
+    GPU call), so that the N Python enqueue loops of an N-GPU job - ~1100 launches per score evaluation each - do not migrate
+    over each other.  cpus: the CPU ids to divide (default: the ones this process may run on).  Returns the block, or None
+    where the platform has no affinity call or there are fewer than two CPUs per rank (the HIP runtime's helper threads need
+    a second one)."""
+    import os
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    avail = sorted(cpus if cpus is not None else os.sched_getaffinity(0))
+    per = len(avail) // max(local_world, 1)
+    if per < 2:
+        return None
+    mine = avail[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
 def gather_results(x_local, fp_local, n_total=None, force_collective=False):
     """x_local [b,L], fp_local [b,P] -> (x_all [n,L], fp_all [n,P]) on every rank, in global clip order.
     Shards may differ by one clip; they are padded to the largest shard for the collective.

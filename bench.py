@@ -79,8 +79,9 @@ def cpu_baseline():
     counts: ALL PHYSICAL CORES of the host (count stated; what 8d asks for), 16 (the fastest setting measured on the 128-core
     hosts of this pool: the many small ops of the reference path do not scale past a few tens of threads - the all-cores
     leg is the number that shows it) and 8 (comparable with the survey's numbers), each with the per-component split.
-    The headline `value` is ONE evaluation at the benchmark's own geometry (368368 samples, no extrapolation in length) at
-    the best of those thread counts, x69; the short-sample legs and their x8 extrapolation are reported beside it."""
+    The headline `value` is ONE WARMED evaluation at the benchmark's own geometry (368368 samples, no extrapolation in length),
+    timed at the best short-sample thread count and at all physical cores (best of the two), x69; the short-sample legs and
+    their x8 extrapolation are reported beside it."""
     from oracle import edm as E
     from oracle import unet as UN
     from oracle.nsgt import CQT_nsgt as OracleCQT
@@ -139,42 +140,69 @@ def cpu_baseline():
     pc = min(phys, logical)
     if pc in legs:
         out["value_all_physical_cores"] = legs[pc]["value"]
-    # one evaluation at the benchmark's own segment length (no length extrapolation), best thread count, no warm-up
+    # The benchmark's own segment length (no length extrapolation): ONE untimed warm-up evaluation (first touch of the ~26 GB
+    # working set, lazy tables), then one timed evaluation at each of two thread counts - the best short-sample count and all
+    # physical cores (the thread choice is re-made at full length, not inherited from the 46046-sample legs); best one counts.
     try:
-        torch.set_num_threads(best)
         smpF, xF, yF, schedF = setup(SEG)
-        params = torch.tensor([list(smpF.fc_init), list(smpF.A_init)], dtype=torch.float32)
-        timers = {}
+        params0 = torch.tensor([list(smpF.fc_init), list(smpF.A_init)], dtype=torch.float32)
+        # second thread count: all physical cores unless the short-sample leg already showed them >= 3x slower than the best
+        # count (128-core hosts of this pool: 10x - a 200 s leg would not fit the default run), then twice the best count
+        pcn = min(phys, logical)
+        second = pcn if legs[pcn]["seconds_per_evaluation"] < 3.0 * dt else min(2 * best, pcn)
+        cand = sorted({best, second})
+        torch.set_num_threads(best)
         t0 = time.perf_counter()
-        smpF.evaluate(xF, schedF[0], yF, params, blind=True, timers=timers)
-        dtF = time.perf_counter() - t0
-        out["full_segment_evaluation"] = {"segment_len": SEG, "threads": best, "seconds": round(dtF, 3),
-                                          "split_seconds": {k: round(v, 4) for k, v in timers.items()},
-                                          "value": (SEG / FS) / (69 * dtF),
-                                          "ratio_to_8x_short_sample": round(dtF / (8 * dt), 3)}
+        smpF.evaluate(xF, schedF[0], yF, params0.clone(), blind=True)       # warm-up (untimed)
+        warm_s = time.perf_counter() - t0
+        full_legs = []
+        for n in cand:
+            if n != best and warm_s > 60.0:
+                continue                                                    # (a slow host: keep the default run within minutes)
+            torch.set_num_threads(n)
+            timers = {}
+            t0 = time.perf_counter()
+            smpF.evaluate(xF, schedF[0], yF, params0.clone(), blind=True, timers=timers)
+            dtn = time.perf_counter() - t0
+            full_legs.append({"threads": n, "seconds": round(dtn, 3), "split_seconds": {k: round(v, 4) for k, v in timers.items()},
+                              "value": (SEG / FS) / (69 * dtn)})
+        bl = max(full_legs, key=lambda e: e["value"])
+        out["full_segment_evaluation"] = dict(bl, segment_len=SEG, warmup_evaluation_seconds=round(warm_s, 3), warmed=True,
+                                              legs=full_legs, ratio_to_8x_short_sample=round(bl["seconds"] / (8 * dt), 3))
     except Exception as e:                                                   # (host memory: ~26 GB)  noqa: BLE001
         out["full_segment_evaluation"] = {"error": f"{type(e).__name__}: {e}"}
-    # The headline `value` is the MEASURED full-geometry evaluation (one score evaluation of a 368368-sample segment, x69);
-    # the short-sample legs and their x8 length extrapolation stay beside it: they under-state the cost of the real
-    # geometry by `ratio_to_8x_short_sample` (2.8-3.1 on the 128-core hosts of this pool: cache footprint of the long rows).
+    # The headline `value` is the MEASURED, WARMED full-geometry evaluation (one score evaluation of a 368368-sample segment,
+    # x69) at its best thread count; the short-sample legs and their x8 length extrapolation stay beside it.
     fse = out["full_segment_evaluation"]
     out["value_extrapolated_from_short_sample"] = out["value"]
     if "value" in fse:
         out["value"] = fse["value"]
+        out["cores"] = fse["threads"]
+        out["seconds_per_evaluation"] = fse["seconds"]
+        out["split_seconds_per_evaluation"] = fse["split_seconds"]
         out["sample"] = (f"ONE score evaluation (UNet fwd + input-VJP, filter fit, filter apply) of a full {SEG}-sample segment at "
-                         f"44.1 kHz, full-width network, {fse['seconds']:.1f} s on {best} threads, x69 evaluations per segment; "
-                         f"thread count = the best of the short-sample legs {sorted(legs)} (46046-sample segment, T=2, beside "
-                         f"this value under `legs`; their x8 length extrapolation is {fse['ratio_to_8x_short_sample']}x too optimistic)")
+                         f"44.1 kHz, full-width network, WARMED (one untimed evaluation first, {fse['warmup_evaluation_seconds']:.1f} s), "
+                         f"{fse['seconds']:.1f} s on {fse['threads']} threads = the best of {[e['threads'] for e in fse['legs']]} threads "
+                         f"timed at full length, x69 evaluations per segment; the short-sample legs {sorted(legs)} (46046-sample "
+                         f"segment, T=2) are beside this value under `legs`; their x8 length extrapolation is "
+                         f"{fse['ratio_to_8x_short_sample']}x of this measurement")
     return out
 
 
-PMC_TRAFFIC_FILE = "r05_conv_traffic.json"
+PMC_TRAFFIC_FILE = "r06_conv_traffic.json"      # falls back to the newest committed file
+
 
 
 def conv_traffic(precision):
     """HBM-side bytes per launch of the dominant conv kernel (conv_wino85_kernel / conv_wino85s_kernel) from the committed PMC passes (rocprofv3 cannot run inside the bench; the
     passes are separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this command, profiles/README.md)."""
+    global PMC_TRAFFIC_FILE
     path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+    if not os.path.exists(path):
+        import glob
+        older = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_conv_traffic.json")))
+        if older:
+            path, PMC_TRAFFIC_FILE = older[-1], os.path.basename(older[-1])
     if precision != "f32" or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -235,10 +263,31 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="conv arithmetic: f32 = exact fp32 MFMA (the benchmark's dtype); bf16x3 / bf16 = bf16 MFMA with "
                          "fp32 storage+accumulation (reported with their own dtype string, never as f32)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the rank -> device -> clip-range table of this command (JSON) and exit: no GPU, no process group")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin this rank's host threads to its own block of CPUs")
     ap.add_argument("--profile-steps", type=int, default=1,
                     help="timed steps whose launches are bracketed by HIP events (0 = no roofline/hbm blocks)")
     a = ap.parse_args()
 
+    if a.dry_run:
+        # the plan only: which rank drives which device and restores which clips of one step (block partition, babe_amd/dist.py);
+        # nothing below touches a GPU or opens a process group
+        from babe_amd.dist import rank_table
+        from babe_amd.testing.long_file import plan_segments
+        n_clips = a.gpus * a.clips_per_gpu
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        per = ncpu // a.gpus
+        rows = [{"rank": r, "device": f"cuda:{d}", "clips": [lo, hi], "n_clips": hi - lo,
+                 "segments": (hi - lo) * len(plan_segments(CLIP, SEG)),
+                 "host_cpus": (f"{r * per}..{(r + 1) * per - 1} of the {ncpu} this process may use" if per >= 2 and not a.no_pin else "unpinned (fewer than 2 CPUs per rank on this host)")}
+                for r, d, lo, hi in rank_table(n_clips, a.gpus, a.gpus)]
+        print(json.dumps({"dry_run": True, "n_gpus": a.gpus, "clips_per_step": n_clips, "partition": "static block (babe_amd.dist.shard_range)",
+                          "collective": "one all_gather_into_tensor of restored audio + filters per step (RCCL); none per EDM step",
+                          "launch": "python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P "
+                                    "bench.py --gpus %d ...  (or plain `python bench.py --gpus %d`, which spawns exactly that as a child)"
+                                    % (a.gpus, a.gpus, a.gpus), "ranks": rows}, indent=1))
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a.gpus))                  # before anything touches the GPU in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -248,6 +297,12 @@ def main():
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                  f"--nproc-per-node {a.gpus} (or without a launcher, which spawns the ranks itself)")
     import torch.distributed as dist
+    pinned = None
+    if world > 1 and not a.no_pin:
+        # one block of host CPUs per rank, before the first GPU call: 8 Python enqueue loops must not migrate over each other
+        from babe_amd.dist import pin_host_threads
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        pinned = pin_host_threads(local_rank % lw, lw)
     ndev = torch.cuda.device_count()
     dev_idx = local_rank % max(ndev, 1)          # (== local_rank on a real N-GPU node; lets 2 ranks share 1 GPU in tests)
     torch.cuda.set_device(dev_idx)
@@ -396,15 +451,13 @@ def main():
                                    "kernel 3/10, the nested F(4,5)xF(4,3) kernel 2/10 of the algorithmic direct-convolution "
                                    "flops that `achieved` counts: a kernel that executes FEWER flops for the same outputs is "
                                    "faster at a LOWER frac - rounds 3-5 read 0.59-0.60 on the F(2,5) kernel at 310 algorithmic "
-                                   "TFLOP/s; frac_if_executing_3_10 = what this launch rate would read on that kernel's flop "
-                                   "count, for comparison across rounds only); algorithmic_frac = achieved / peak.  "
+                                   "TFLOP/s); algorithmic_frac = achieved / peak.  "
                                    "`achieved` / `frac` / `avg_launch_us` are the kernel ALONE on the GPU (the `serial` "
                                    "block: all batch items on one stream, what the rocprofv3 summary under profiles/ "
                                    "reproduces) when that block exists; the same launches inside the two-lane timed region, "
                                    "whose durations include the other lane's kernels, are under `timed_region`",
                 "algorithmic_frac": round(r["flops"] / sec / 1e12 / peak, 4),
                 "executed_tflops": round(r["exec_flops"] / sec / 1e12, 2),
-                "frac_if_executing_3_10": (round(0.3 * r["flops"] / sec / 1e12 / peak, 4) if dom == "conv53_wino85" else None),
                 "traffic": (tr or {}).get("bytes_per_launch"), "traffic_detail": tr,
                 "algorithmic_MB_per_launch": round(r["bytes"] / r["launches"] / 1e6, 2),
                 "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
@@ -430,14 +483,28 @@ def main():
                     "avg_launch_us": round(q["ms"] * 1e3 / q["launches"], 2), "launches": q["launches"],
                     "sum_kernel_time_over_wall": round(sum(v["ms"] for v in serial.values()) * 1e-3 / t_ser, 4),
                     "all_conv_kernels": slot_table(serial, CONV_SLOTS, t_ser)}
-                # headline figures = the kernel alone (reproducible from profiles/); the overlapped ones move beside them
-                roof["timed_region"] = {k: roof[k] for k in ("achieved", "frac", "algorithmic_frac", "executed_tflops",
-                                                             "avg_launch_us", "launches")}
+                # headline figures = the kernel alone (reproducible from profiles/); the overlapped ones move beside them.  EVERY
+                # per-launch field moves with them, so that achieved = algorithmic_gflop_per_launch_avg / avg_launch_us holds
+                # inside the line (the serial step launches each layer ONCE for the whole batch, the timed region once per lane)
+                per_launch = ("achieved", "frac", "algorithmic_frac", "executed_tflops", "avg_launch_us", "launches",
+                              "algorithmic_gflop_per_launch_avg", "algorithmic_MB_per_launch")
+                roof["timed_region"] = {k: roof[k] for k in per_launch}
                 sr = roof["serial"]
-                if dom == "conv53_wino85":               # the same outputs per second on the round-4 algorithm (3/10 executed) would read this frac
-                    roof["frac_if_executing_3_10"] = round(0.3 * q["flops"] / qs / 1e12 / peak, 4)
+                if dom == "conv53_wino85":               # cross-round comparison only: the same outputs per second on the round-4 algorithm (3/10 executed)
+                    roof["cross_round_comparison"] = {"frac_if_this_rate_executed_3_10": round(0.3 * q["flops"] / qs / 1e12 / peak, 4),
+                                                      "note": "hypothetical, NOT an achieved utilisation: rounds 3-5a read 0.59-0.60 on the "
+                                                              "F(2,5)xF(4,3) kernel, which executes 3/10 of the algorithmic flops"}
                 roof.update(achieved=sr["achieved"], frac=sr["frac"], algorithmic_frac=sr["algorithmic_frac"],
-                            executed_tflops=round(q["exec_flops"] / qs / 1e12, 2), avg_launch_us=sr["avg_launch_us"])
+                            executed_tflops=round(q["exec_flops"] / qs / 1e12, 2), avg_launch_us=sr["avg_launch_us"],
+                            launches=q["launches"], algorithmic_gflop_per_launch_avg=round(q["flops"] / q["launches"] / 1e9, 3),
+                            algorithmic_MB_per_launch=round(q["bytes"] / q["launches"] / 1e6, 2))
+                if tr:
+                    # the PMC passes trace one-segment launches; a serial launch carries the whole batch: same unit as `achieved`
+                    nb = nseg * C_
+                    roof["traffic"] = round(tr["bytes_per_launch"] * nb)
+                    roof["traffic_over_algorithmic"] = round(roof["traffic"] / (q["bytes"] / q["launches"]), 3)
+                    roof["traffic_detail"] = dict(tr, segments_per_launch_here=nb,
+                                                  note="bytes_per_launch is per ONE-segment launch; `traffic` = x segments per launch")
             hbm = {"peak_GB_per_s": HBM_PEAK_GBS, "bytes": "ALGORITHMIC bytes per launch (each operand touched once), DESIGN.md 3",
                    "timed_region": slot_table(timed, HBM_SLOTS, wall_prof)}
             if serial is not None:
@@ -457,6 +524,7 @@ def main():
                        "parallelism": "clips sharded over %d GPU(s), one process per GPU, %s" % (
                            world, "no collective (single rank, no launcher)" if not (world > 1 or launched) else
                            "%s all_gather at end of step" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())),
+                       "host_cpus_rank0": (f"pinned to {len(pinned)} CPUs ({pinned[0]}..{pinned[-1]})" if pinned else "unpinned"),
                        "hip_graphs": "none: eager launch loop, no host sync inside a step (the opt-in graph replay of rounds 2-4 "
                                      "measured 2.129 vs 2.140 audio-sec/s on this command and was removed in round 5)",
                        "headline": a.T == 35 and a.precision == "f32" and C_ == 1},
