@@ -780,10 +780,9 @@ extern "C" int babe_conv_pack_weights_wino85(const float* w, float* dst, int Cou
     return BABE_OK;
 }
 
-/* 1 if the F(4,5) x F(4,3) kernel can run this problem: 128-channel output tiles, 16-channel input slabs, T a multiple of 4 and at
- * least 64, one source, 16-byte aligned views.  (A 96-channel tile - six multiplying waves of eight - was built and measured:
- * 0.75x the F(2,5) x F(4,3) kernel on the 96-channel layers, whose 12 (tile, segment) items balance over the four SIMDs where
- * this kernel's six cannot; profiles/r05_f45_check.txt.) */
+/* 1 if the F(4,5) x F(4,3) kernels can run this problem (the contract include/babe_hip.h states): Cout a multiple of 128
+ * (conv_wino85_kernel), 96 or 64 (conv_wino85s_kernel<., 6> / <., 4>: specialised multiplying / transform waves), Cin a multiple
+ * of 16, T a multiple of 4 and at least 64, one source, 16-byte aligned views. */
 extern "C" int babe_conv2d_wino85_supported(const babe_conv_args* ap) {
     if (!ap) return 0;
     const babe_conv_args& a = *ap;

@@ -13,6 +13,7 @@ apply_denoiser on the whole file -> exp.sample_rate, then the BWE on its output)
 """
 import argparse
 import os
+import sys
 
 import torch
 
@@ -53,15 +54,19 @@ def main():
         dnet = MultiStage_denoise(dargs)
         if a.denoiser_ckpt:
             dnet.load_state_dict(torch.load(a.denoiser_ckpt, map_location="cpu"))
-        # denoise_and_bwe_tester.py:279-289 (both conversions hang on fs != sample_rate_denoiser there; a file already at the
-        # denoiser's rate still has to reach the model's rate here, or the segment lengths below would not be the model's)
-        if sr != a.denoiser_rate:
-            y = resample(y, sr, a.denoiser_rate)
-        y = DenoiserPrepass(dnet.to("cuda"), dargs, "cuda").apply_denoiser(y.unsqueeze(0))[0]
-        if a.denoiser_rate != a.sample_rate:
-            y = resample(y, a.denoiser_rate, a.sample_rate)
-    else:
-        y = resample(y, sr, a.sample_rate)                   # blind_bwe_tester.py:410 (the input itself at equal rates)
+        prepass = DenoiserPrepass(dnet.to("cuda"), dargs, "cuda")
+    # one rule for both file-level entry points (long_file.rate_plan): the reference's, quirk included - a file already at the
+    # denoiser's rate goes to the model unconverted (denoise_and_bwe_tester.py:279-289)
+    from .testing.long_file import rate_plan
+    plan = rate_plan(sr, a.sample_rate, a.denoiser_rate if a.denoise else None)
+    if a.denoise and sr == a.denoiser_rate and sr != a.sample_rate:
+        print(f"warning: the file is at the denoiser's rate ({sr} Hz): as in the reference it reaches the {a.sample_rate} Hz model "
+              f"unconverted; resample it first if that is not intended", file=sys.stderr)
+    for step in plan:
+        if step == "denoise":
+            y = prepass.apply_denoiser(y.unsqueeze(0))[0]
+        else:
+            y = resample(y, step[0], step[1])
     std = float(y.std())
     y = y * (a.sigma_norm / std)
     sampler = BlindSampler(net, EDM(args), args, batch_semantics="per_clip")

@@ -122,6 +122,21 @@ def restore_file_AR(sampler, y, filt, filt_type="fc_A", overlap_s=0.25, discard_
     return out
 
 
+def rate_plan(fs, sample_rate, denoiser_rate=None):
+    """The sample-rate conversions of the file-level flows as a list of (from, to) pairs, in order, with the string
+    "denoise" where the denoiser runs - ONE rule for `restore_recording_complete` and `python -m babe_amd.restore`:
+      * no denoiser: fs -> exp.sample_rate (testing/blind_bwe_tester.py:410; nothing at equal rates);
+      * with a denoiser, the reference's own rule (testing/denoise_and_bwe_tester.py:279-289): fs -> denoiser rate before it
+        and denoiser rate -> exp.sample_rate after it, BOTH only `if fs != sample_rate_denoiser`.  The quirk that comes with
+        it is kept, not repaired: a file already AT the denoiser's rate reaches the model unconverted even when the model's
+        rate differs - exactly what the reference does with such a file."""
+    if denoiser_rate is None:
+        return [(fs, sample_rate)] if fs != sample_rate else []
+    if fs == denoiser_rate:
+        return ["denoise"]
+    return [(fs, denoiser_rate), "denoise", (denoiser_rate, sample_rate)]
+
+
 def restore_recording_complete(sampler, degraded, *, n_segments_blindstep=1, ix_start=0, std=0.1, overlap_s=0.25,
                                typefilter="fc_A", denoiser=None, rng=None, fs=None, sample_rate_denoiser=None):
     """Whole-recording flow of BlindTester.test_real_blind_bwe_complete (/root/reference/testing/blind_bwe_tester.py:
@@ -147,17 +162,16 @@ def restore_recording_complete(sampler, degraded, *, n_segments_blindstep=1, ix_
     args = sampler.args
     segL = args.exp.audio_len
     d = degraded.reshape(1, -1).float()
-    if fs is not None:
-        from ..resample import resample
+    srd = None
     if denoiser is not None:
         srd = sample_rate_denoiser if sample_rate_denoiser is not None else denoiser._get("sample_rate_denoiser")
-        if fs is not None and fs != srd:
-            d = resample(d, fs, srd)
-        d = denoiser.apply_denoiser(d)
-        if fs is not None and fs != srd:
-            d = resample(d, srd, args.exp.sample_rate)
-    elif fs is not None:
-        d = resample(d, fs, args.exp.sample_rate)
+    # (fs None: the caller states that the file is already where it has to be - only the denoiser runs)
+    for step in (rate_plan(fs, args.exp.sample_rate, srd) if fs is not None else (["denoise"] if denoiser is not None else [])):
+        if step == "denoise":
+            d = denoiser.apply_denoiser(d)
+        else:
+            from ..resample import resample
+            d = resample(d, step[0], step[1])
     s = d.std(-1)
     d = std * d / s.unsqueeze(-1)
     L = d.shape[-1]

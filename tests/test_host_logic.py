@@ -231,3 +231,15 @@ def test_bench_gpus_flag_without_launcher_spawns_ranks_or_fails_loudly(monkeypat
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code not in (0, None) and calls == [4]
+
+
+def test_rate_plan_is_the_references_rule_for_both_entry_points():
+    """testing/blind_bwe_tester.py:410 and testing/denoise_and_bwe_tester.py:279-289: without a denoiser fs -> model rate; with
+    one, both conversions hang on fs != sample_rate_denoiser (a file at the denoiser's rate goes to the model unconverted)."""
+    from babe_amd.testing.long_file import rate_plan
+    assert rate_plan(44100, 44100) == []
+    assert rate_plan(48000, 44100) == [(48000, 44100)]
+    assert rate_plan(48000, 16000, 22050) == [(48000, 22050), "denoise", (22050, 16000)]
+    assert rate_plan(22050, 16000, 22050) == ["denoise"]                       # the reference's quirk, kept
+    assert rate_plan(22050, 22050, 22050) == ["denoise"]
+    assert rate_plan(16000, 16000, 22050) == [(16000, 22050), "denoise", (22050, 16000)]

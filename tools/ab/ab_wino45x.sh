@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the second-generation wide nested-Winograd kernel (conv_wino45x) against the first (BABE_CONV_WINO45X=0), same box.
-# usage (through gpurun): tools/ab_wino45x.sh <outdir-name>
+# usage (through gpurun): tools/ab/ab_wino45x.sh <outdir-name>
 out=gpurun_out/$1
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT

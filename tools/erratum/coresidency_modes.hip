@@ -1,10 +1,10 @@
 // Where does the co-residency corruption come from?  Three reduced victims beside the library's 64-channel bf16 conv
-// (babe_conv2d_bf16, conv_bf16p G = 2: 256 threads, 57 KB LDS, two workgroups per CU), see tools/coresidency_repro.hip:
+// (babe_conv2d_bf16, conv_bf16p G = 2: 256 threads, 57 KB LDS, two workgroups per CU), see tools/erratum/coresidency_repro.hip:
 //   lds_watch  : every workgroup writes a pattern to 20 KB of LDS and re-reads it for a while: mismatches = somebody else wrote
 //                into this workgroup's LDS
 //   pk_alu     : registers only, v_pk_fma_f32 chains (no LDS, no memory in the loop): wrong = the arithmetic itself is disturbed
 //   conv_nolds : the repro victim with its taps read from global memory (scalar loads) instead of LDS
-// Build: hipcc --offload-arch=gfx950 -O3 tools/coresidency_modes.hip -o tools/bin/coresidency_modes -Lbabe_amd -lbabe_hip -Wl,-rpath,$PWD/babe_amd
+// Build: hipcc --offload-arch=gfx950 -O3 tools/erratum/coresidency_modes.hip -o tools/bin/coresidency_modes -Lbabe_amd -lbabe_hip -Wl,-rpath,$PWD/babe_amd
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>

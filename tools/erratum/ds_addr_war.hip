@@ -1,5 +1,5 @@
 // Is overwriting the ADDRESS register of an LDS read before s_waitcnt lgkmcnt(0) safe on gfx950?
-// hipcc emits exactly that in the packed-fp32 build of tools/coresidency_repro.hip's victim:
+// hipcc emits exactly that in the packed-fp32 build of tools/erratum/coresidency_repro.hip's victim:
 //     ds_read_b96 v[30:32], v22 ; s_waitcnt vmcnt(0) ; ... ; v_mov_b32 v22, v7 ; s_waitcnt lgkmcnt(0)
 // This program runs that sequence by hand (inline asm), alone and beside the library's 64-channel bf16 conv, and checks the data
 // the read returned against the LDS contents (word i holds i).  Variants:
@@ -8,7 +8,7 @@
 //   2 b96+vm  : the victim's shape: a global load in flight, s_waitcnt vmcnt(0) between the read and the overwrite
 //   3 b128    : variant 1 with ds_read_b128
 //   4 b32     : variant 1 with ds_read_b32
-// Build: hipcc --offload-arch=gfx950 -O3 tools/ds_addr_war.hip -o tools/bin/ds_addr_war -Lbabe_amd -lbabe_hip -Wl,-rpath,$PWD/babe_amd
+// Build: hipcc --offload-arch=gfx950 -O3 tools/erratum/ds_addr_war.hip -o tools/bin/ds_addr_war -Lbabe_amd -lbabe_hip -Wl,-rpath,$PWD/babe_amd
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>

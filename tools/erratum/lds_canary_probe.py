@@ -1,4 +1,4 @@
-"""Does conv_bf16p write into LDS that belongs to another workgroup?  Runs an LDS canary kernel (tools/lds_canary.hip, compiled
+"""Does conv_bf16p write into LDS that belongs to another workgroup?  Runs an LDS canary kernel (tools/erratum/lds_canary.hip, compiled
 here with hipcc) on one stream beside bf16 / fp32 conv launches on another and prints what changed in the canaries' LDS."""
 import ctypes as C, math, os, subprocess, sys, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
