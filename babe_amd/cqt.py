@@ -135,12 +135,41 @@ class _BandsStruct(C.Structure):
                 ("wg_first", C.c_void_p), ("wg_count", C.c_void_p), ("nwg", C.c_int),
                 ("wg_rec", C.c_void_p), ("band_rec", C.c_void_p), ("abl", C.c_int),
                 ("max_wg_count", C.c_int), ("min_log2T", C.c_int), ("max_log2T", C.c_int),
-                ("sum_T", C.c_long), ("sum_M", C.c_long), ("sum_TlogT", C.c_double)]
+                ("sum_T", C.c_long), ("sum_M", C.c_long), ("sum_TlogT", C.c_double),
+                ("kdeg", C.c_int), ("kpoly", C.c_float * 12)]
+
+
+def kaiser_poly(beta, tol=1e-9, max_deg=11):
+    """Coefficients of the truncated power series I0(beta sqrt(a)) / I0(beta) = sum_j (beta^2/4)^j / (j!)^2 / I0(beta) a^j for
+    a in [0, 1] (include/babe_hip.h, babe_cqt_bands::kpoly): smallest degree whose first dropped term is below `tol`
+    (beta = 1: degree 5); None when that needs more than `max_deg` terms (the kernels then read the window table)."""
+    q = beta * beta / 4.0
+    terms, t, j = [1.0], 1.0, 0
+    while True:
+        j += 1
+        t = t * q / (j * j)
+        if t < tol:
+            break
+        terms.append(t)
+        if j > max_deg:
+            return None
+    deg = max(len(terms) - 1, 1)
+    co = np.zeros(12)
+    co[:len(terms)] = np.asarray(terms) / float(np.i0(beta))
+    return deg, co
 
 
 def _register_sigs():
     L = lib()
     P, I, F, Lg = C.c_void_p, C.c_int, C.c_float, C.c_long
+    L.babe_cqt_plan_create.restype = P
+    L.babe_cqt_plan_create.argtypes = [C.c_double, I, I, I, C.c_double]
+    L.babe_cqt_plan_destroy.argtypes = [P]
+    L.babe_cqt_workspace_bytes.restype = Lg
+    L.babe_cqt_workspace_bytes.argtypes = [P, I]
+    for n in ("babe_cqt_fwd", "babe_cqt_bwd", "babe_cqt_fwd_adjoint", "babe_cqt_bwd_adjoint", "babe_cqt_hpf"):
+        getattr(L, n).restype = I
+        getattr(L, n).argtypes = [P, P, P, P, I, P]
     L.babe_fft_twiddle_transpose.argtypes = [P, P, P, I, I, I, I, P]
     L.babe_rfft_mixed.argtypes = [P, P, P, P, P, I, I, I, I, P, I, P, I, P, P, P, I, P]
     L.babe_rfft_mixed.restype = C.c_int
@@ -303,6 +332,9 @@ class CQT_nsgt:
         q = np.arange(2048, dtype=np.float64)
         self.tw4096 = tf(np.stack([np.cos(2 * np.pi * q / 4096), -np.sin(2 * np.pi * q / 4096)], -1)).contiguous()
         g, gd, Tw = d["g"], d["gdual"], d["Tw"]
+        # the Kaiser window itself (analysis window of fwd, synthesis-side window of fwd's adjoint) is evaluated INSIDE the band
+        # kernels (win = None below; BABE_CQT_ANALYTIC_WIN=0 reads the table); the dual-window tables cannot be
+        self.kaiser = kaiser_poly(float(window[1])) if os.environ.get("BABE_CQT_ANALYTIC_WIN", "1") != "0" else None
         self.win_fwd = tf(g / Tw)                         # analysis window incl. the IFFT's 1/T
         self.win_bwd = tf(gd * Tw)                        # synthesis: T * dual window
         self.win_fwd_adj = tf(g / Tw)                     # adjoint of analysis (synthesis-type kernel)
@@ -326,6 +358,32 @@ class CQT_nsgt:
         cw[0] = cw[-1] = 1.0 / L
         self.hpf_irfft = tf(d["hpf"] * cw)                # hpf * c_k / L   (irfft weights folded in)
         self.irfft_w = tf(cw)
+        # BABE_CQT_C=1: every transform below is ONE call into the library's own plan (csrc/cqt_plan.hip: band design in C++, device
+        # tables, sequencing) - the path a non-Python host takes; default: this class sequences the kernels from the numpy design
+        self._plan = None
+        if os.environ.get("BABE_CQT_C", "0") == "1":
+            self._plan = lib().babe_cqt_plan_create(float(fs), self.Ls, numocts, binsoct, float(window[1]))
+            if not self._plan:
+                check(-1, "cqt_plan_create")
+            self._ws = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None):
+                lib().babe_cqt_plan_destroy(self._plan)
+                self._plan = None
+        except Exception:                                                     # interpreter shutdown  noqa: BLE001
+            pass
+
+    def _plan_call(self, name, a, b, B):
+        """a / b: a device tensor or a list of per-octave tensors (passed as an array of pointers), in the entry point's order."""
+        key = (B, torch.cuda.current_stream().cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = torch.empty(lib().babe_cqt_workspace_bytes(self._plan, B) // 4 + 1, device=self.device)
+            self._ws[key] = ws
+        conv = lambda v: (C.c_void_p * len(v))(*[ptr(t) for t in v]) if isinstance(v, (list, tuple)) else ptr(v)
+        check(getattr(lib(), name)(self._plan, conv(a), conv(b), ptr(ws), B, stream()), name)
 
     # ------------------------------------------------------------------ internals
     def _bands(self, coefs):
@@ -341,6 +399,10 @@ class CQT_nsgt:
         s.nocts, s.binsoct = self.numocts, self.binsoct
         s.sum_T, s.sum_M = int(np.sum(d["T"])), int(np.sum(d["M"]))
         s.sum_TlogT = float(np.sum(d["T"] * np.log2(d["T"])))
+        if self.kaiser is not None:
+            s.kdeg = int(self.kaiser[0])
+            for j in range(12):
+                s.kpoly[j] = float(self.kaiser[1][j])
         for j, cf in enumerate(coefs):
             assert cf.is_contiguous() and cf.shape[1:] == (2, self.binsoct, self.T_oct[j]), cf.shape
             s.coef[j] = ptr(cf)
@@ -353,6 +415,7 @@ class CQT_nsgt:
         B = spec.shape[0]
         coefs = coefs or self.alloc_coefs(B)
         s = self._bands(coefs)
+        win = None if (win is self.win_fwd and self.kaiser is not None) else win
         check(lib().babe_cqt_band_analysis(C.byref(s), ptr(spec), ptr(win), B, stream()), "cqt_band_analysis")
         return coefs
 
@@ -360,6 +423,7 @@ class CQT_nsgt:
         B = coefs[0].shape[0]
         s = self._bands(coefs)
         bs = torch.empty(B, self.nwin, 2, device=self.device)
+        win = None if (win is self.win_fwd_adj and self.kaiser is not None) else win
         check(lib().babe_cqt_band_synthesis(C.byref(s), ptr(bs), ptr(win), self.nwin, B, stream()), "cqt_band_synthesis")
         if spec is None:
             spec = torch.empty(B, 2, self.fft.KX, device=self.device)
@@ -377,17 +441,35 @@ class CQT_nsgt:
     # ------------------------------------------------------------------ planar API (used by the UNet)
     def fwd_planar(self, x):
         """x [B,L] -> list of planar coefficient tensors [B,2,binsoct,T_j] (index 0 = lowest octave)."""
+        if self._plan:
+            x = x.contiguous()
+            co = self.alloc_coefs(x.shape[0])
+            self._plan_call("babe_cqt_fwd", x, co, x.shape[0])
+            return co
         return self.analysis(self.fft.rfft(x), self.win_fwd)
 
     def bwd_planar(self, coefs):
+        if self._plan:
+            x = torch.empty(coefs[0].shape[0], self.Ls, device=self.device)
+            self._plan_call("babe_cqt_bwd", [c.contiguous() for c in coefs], x, x.shape[0])
+            return x
         return self.fft.rfft_T(self.synthesis_spec(coefs, self.win_bwd, 2.0 / self.Ls))
 
     def fwd_adjoint(self, gcoefs):
         """(fwd_planar)^T : gradients w.r.t. coefficients -> gradient w.r.t. x."""
+        if self._plan:
+            gx = torch.empty(gcoefs[0].shape[0], self.Ls, device=self.device)
+            self._plan_call("babe_cqt_fwd_adjoint", [c.contiguous() for c in gcoefs], gx, gx.shape[0])
+            return gx
         return self.fft.rfft_T(self.synthesis_spec(gcoefs, self.win_fwd_adj, 1.0))
 
     def bwd_adjoint(self, gx):
         """(bwd_planar)^T : gradient w.r.t. x -> gradients w.r.t. coefficients."""
+        if self._plan:
+            gx = gx.contiguous()
+            co = self.alloc_coefs(gx.shape[0])
+            self._plan_call("babe_cqt_bwd_adjoint", gx, co, gx.shape[0])
+            return co
         return self.analysis(self.fft.rfft(gx), self.win_bwd_adj)
 
     # ------------------------------------------------------------------ reference API (complex tensors)
@@ -410,5 +492,10 @@ class CQT_nsgt:
             xp = torch.zeros(x.shape[0], L, device=self.device)
             xp[:, : x.shape[-1]] = x
             x = xp
+        if self._plan:
+            x = x.contiguous()
+            out = torch.empty_like(x)
+            self._plan_call("babe_cqt_hpf", x, out, x.shape[0])
+            return out
         spec = self.fft.rfft(x.contiguous())
         return self.fft.rfft_T(self.spec_scale(spec, self.hpf_irfft))

@@ -19,9 +19,18 @@ namespace {
 // is bit-reversed.  One LDS buffer between passes: write - barrier - read - barrier.
 // Element i of the workgroup's image lives at i + (i >> 4) (the first pass writes with stride 16: without the pad all lanes
 // of a wave hit two banks).
+#ifndef ABL
+#define ABL 0     // timing ablations of band_fft_kernel<0> (tools/ab/abl_build.sh cqt <bits>; results are WRONG with any bit set):
+#endif            // 1 wide (16-byte) loads of the same bytes, 2 wide stores, 4 no window loads, 8 no FFT (copy only),
+                  // 16 half the LDS image (indices wrap: more workgroups per CU), 32 register cap for 6 waves per SIMD,
+                  // 128 non-temporal spectrum loads (slower: 41 -> 50 us)
+#if ABL & 16
+#define CQ_AT(i) (((i) + ((i) >> 4)) & 2047)
+#else
 #define CQ_AT(i) ((i) + ((i) >> 4))
+#endif
 constexpr int CQ_PTS = 4096;                           // points per workgroup
-constexpr int CQ_LDS = CQ_PTS + (CQ_PTS >> 4);         // float2 elements
+constexpr int CQ_LDS = (ABL & 16) ? 2048 : CQ_PTS + (CQ_PTS >> 4);         // float2 elements
 
 // Complex values are 2-vectors (register pairs): hipcc turns the arithmetic below into packed fp32 instructions
 // (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) plus some moves of the halves.  (Round 3 tried the same operations as inline
@@ -217,6 +226,26 @@ __device__ __forceinline__ void cq_band_fft_regs(f2* v, f2* a, const f2* __restr
     }
 }
 
+// Kaiser window g(m) / T of a band of M samples, m = -(M/2) .. M - M/2 - 1 (include/babe_hip.h, babe_cqt_bands::kpoly):
+// Horner over a = 1 - (2 m / M)^2 with the coefficients in scalar registers
+struct CqKaiser { float c[12]; int deg; float tom; };     // coefficients in (scalar) registers, 2 / M of the thread's band
+template <int LT>
+__device__ __forceinline__ float cq_kaiser(const CqKaiser& kz, int m) {
+    const float x = (float)m * kz.tom;
+    const float a = fmaxf(fmaf(-x, x, 1.f), 0.f);
+    float p;                                           // (entries above deg are zero; the branch is uniform)
+    if (kz.deg <= 6) {
+        p = kz.c[6];
+#pragma unroll
+        for (int j = 5; j >= 0; --j) p = fmaf(p, a, kz.c[j]);
+    } else {
+        p = kz.c[11];
+#pragma unroll
+        for (int j = 10; j >= 0; --j) p = fmaf(p, a, kz.c[j]);
+    }
+    return p * (1.f / (float)(1 << LT));
+}
+
 // ANALYSIS (MODE 0): x[pos] = spec[(c + m) mod L] * win[m], m = pos for pos < M - M/2, pos - T for pos >= T - M/2, 0 between;
 // IFFT_T (unnormalised; win carries 1/T); coefficients out planar.
 // SYNTHESIS (MODE 1): x = coefficients; FFT_T; bs[woff + mi] = X[(mi - M/2) mod T] * win[mi].
@@ -225,7 +254,7 @@ __device__ __forceinline__ void cq_band_fft_regs(f2* v, f2* a, const f2* __restr
 // the last pass are stored from registers (runs of Ns >= 16 consecutive samples per instruction).  Round 2 staged the band
 // through LDS before the first and after the last pass and kept the twiddle table in LDS: 256 KB of LDS traffic + 100 KB of
 // twiddle reads + a 16 KB table copy per 4096 points - at B >= 32 the kernel was bound by LDS, not HBM.  Now 128 KB.
-template <int LT, int MODE>
+template <int LT, int MODE, bool AN, bool NT>
 __device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, int nb, int oc, int bin0, int b,
                                        const float* __restrict__ spec, float* __restrict__ bs, long bs_stride,
                                        const float* __restrict__ win) {
@@ -243,6 +272,12 @@ __device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, 
     const i32x4 br = reinterpret_cast<const i32x4*>(bd.band_rec)[k];          // {c, M, woff, 0}
     const int M = br[1], wo = br[2], half = M >> 1;
     const f2* tw = reinterpret_cast<const f2*>(bd.tw4096);
+    constexpr bool analytic = AN;                         // Kaiser window evaluated here instead of read
+    CqKaiser kz;
+    kz.c[0] = bd.kpoly[0]; kz.c[1] = bd.kpoly[1]; kz.c[2] = bd.kpoly[2]; kz.c[3] = bd.kpoly[3]; kz.c[4] = bd.kpoly[4]; kz.c[5] = bd.kpoly[5];
+    kz.c[6] = bd.kpoly[6]; kz.c[7] = bd.kpoly[7]; kz.c[8] = bd.kpoly[8]; kz.c[9] = bd.kpoly[9]; kz.c[10] = bd.kpoly[10]; kz.c[11] = bd.kpoly[11];
+    kz.deg = bd.kdeg;
+    kz.tom = 2.f / (float)M;
     // All global traffic goes through buffer descriptors: 32-bit per-thread offsets, the compile-time part of an address in
     // the instruction's scalar offset, the range check as the "outside the window" zero - the kernel is bound by the
     // vector ALU (round 3 PMC: 1100 vector instructions per thread and 16 points, a third of them address arithmetic).
@@ -258,7 +293,23 @@ __device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, 
         const unsigned im = (unsigned)bd.KX * 4;
         float vr[R0], vi[R0], vw[R0];
         // the band's window covers spectrum bins c - half .. c + M - half - 1; almost every band lies inside 0 .. L/2
-        if (c - half >= 0 && c + M - half - 1 <= bd.L / 2) {
+        if ((ABL & 1) && R0 == 16) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const unsigned so = active ? (unsigned)(c + 4 * u + t4 * 4 * TB) * 4 : OOB;
+                const unsigned wv = active ? (unsigned)(wo + 4 * u + t4 * 4 * TB) * 4 : OOB;
+                const f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, so, 0, 0));
+                const f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, so, im, 0));
+                const f32x4 a2 = (ABL & 4) ? f32x4{1.f, 1.f, 1.f, 1.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wv, 0, 0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vr[4 * t4 + i] = a0[i];
+                    vi[4 * t4 + i] = a1[i];
+                    vw[4 * t4 + i] = a2[i];
+                }
+            }
+        } else if (c - half >= 0 && c + M - half - 1 <= bd.L / 2) {
 #pragma unroll
             for (int t = 0; t < R0; ++t) {
                 const int pos = u + t * TB;
@@ -267,9 +318,10 @@ __device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, 
                 const int m = hi ? pos - T : pos;
                 const unsigned so = in ? (unsigned)(c + m) * 4 : OOB;
                 const unsigned wv = in ? (unsigned)(wo + half + m) * 4 : OOB;
-                vr[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, 0, 0));
-                vi[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, im, 0));
-                vw[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wv, 0, 0));
+                vr[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, 0, (ABL & 128) ? 2 : 0));
+                vi[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, im, (ABL & 128) ? 2 : 0));
+                if (analytic) vw[t] = cq_kaiser<LT>(kz, m);       // (outside the window the spectrum loads return 0)
+                else vw[t] = (ABL & 4) ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wv, 0, 0));
             }
         } else {                                          // bands that wrap around bin 0 or reach past L/2 (mirror: conjugate)
 #pragma unroll
@@ -286,7 +338,8 @@ __device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, 
                 const unsigned wv = in ? (unsigned)(wo + half + m) * 4 : OOB;
                 vr[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, 0, 0));
                 vi[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, im, 0));
-                vw[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wv, 0, 0));
+                if (analytic) vw[t] = cq_kaiser<LT>(kz, m);
+                else vw[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wv, 0, 0));
                 if (mir) vi[t] = -vi[t];
             }
         }
@@ -302,8 +355,19 @@ __device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, 
 #pragma unroll
         for (int t = 0; t < R0; ++t) v[t] = f2{vr[t], vi[t]};
     }
-    cq_band_fft_regs<LT, (MODE == 0 ? +1 : -1)>(v, a, tw, s << LT, u, active);
-    if (MODE == 0) {
+    if (!(ABL & 8) || MODE != 0) cq_band_fft_regs<LT, (MODE == 0 ? +1 : -1)>(v, a, tw, s << LT, u, active);
+    if (MODE == 0 && (ABL & 2) && R0 == 16) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const unsigned o0 = cfo + (unsigned)(4 * u + t4 * 4 * TB) * 4;
+            const f32x4 yr = {v[4 * t4].x, v[4 * t4 + 1].x, v[4 * t4 + 2].x, v[4 * t4 + 3].x};
+            const f32x4 yi = {v[4 * t4].y, v[4 * t4 + 1].y, v[4 * t4 + 2].y, v[4 * t4 + 3].y};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, yr), rc, o0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, yi), rc, o0, plane, 0);
+        }
+    } else if (MODE == 0) {
 #pragma unroll
         for (int c = 0; c < PL::CNT; ++c) {
             const unsigned o0 = cfo + (unsigned)PL::out_index(u, c, 0) * 4;                // (cq_perm(0) = 0)
@@ -312,8 +376,10 @@ __device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, 
                 const int d = cq_perm<PL::R>(r) * PL::Ns * 4;
                 // (floats first: hipcc 7.2 miscompiles __builtin_bit_cast of an ext_vector ELEMENT - it reads element 0)
                 const float yr = v[c * PL::R + r].x, yi = v[c * PL::R + r].y;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(yr), rc, o0, d, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(yi), rc, o0, plane + d, 0);
+                // (NT: non-temporal stores from 8 clips on - the coefficients of a large batch are read much later, by the UNet's
+                // first convolutions, and need not displace the spectrum in L2: -3.4 % at 32 clips, profiles/r06_cqt_bench.txt)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(yr), rc, o0, d, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(yi), rc, o0, plane + d, NT ? 2 : 0);
             }
         }
     } else {
@@ -326,15 +392,20 @@ __device__ __forceinline__ void cq_run(const babe_cqt_bands& bd, f2* a, int k0, 
             for (int r = 0; r < PL::R; ++r) {
                 const int mi = (PL::out_index(u, c, r) + half) & (T - 1);
                 const bool ok = active && mi < M;
-                const float w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, ok ? (unsigned)(wo + mi) * 4 : OOB, 0, 0));
+                const float w = analytic ? cq_kaiser<LT>(kz, mi - half)
+                                         : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, ok ? (unsigned)(wo + mi) * 4 : OOB, 0, 0));
                 const f2 o = v[c * PL::R + r] * w;
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, o), ro, ok ? (unsigned)(wo + mi) * 8 : OOB, 0, 0);
             }
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void band_fft_kernel(babe_cqt_bands bd, const float* __restrict__ spec,
+template <int MODE, bool AN, bool NT>
+__global__ __launch_bounds__(256)
+#if ABL & 32
+__attribute__((amdgpu_waves_per_eu(6, 6)))
+#endif
+void band_fft_kernel(babe_cqt_bands bd, const float* __restrict__ spec,
                                                        float* __restrict__ bs, long bs_stride,
                                                        const float* __restrict__ win) {
     __shared__ f2 a[CQ_LDS];
@@ -344,7 +415,7 @@ __global__ __launch_bounds__(256) void band_fft_kernel(babe_cqt_bands bd, const 
     const int k0 = wr[0], nb = wr[1], lt = wr[2], oc = wr[3] & 255, bin0 = wr[3] >> 8;
     if (nb > 64 || (nb << lt) > 4096 || oc >= 8) __builtin_trap();      // a table that contradicts its own summary fields: fail loudly
     switch (lt) {
-#define CQ_CASE(L_) case L_: cq_run<L_, MODE>(bd, a, k0, nb, oc, bin0, b, spec, bs, bs_stride, win); break;
+#define CQ_CASE(L_) case L_: cq_run<L_, MODE, AN, NT>(bd, a, k0, nb, oc, bin0, b, spec, bs, bs_stride, win); break;
 #ifdef CQ_ONLY                    // (instruction counting: one band length per build)
         CQ_CASE(CQ_ONLY)
 #else
@@ -553,10 +624,15 @@ static int check_bands(const babe_cqt_bands* bd) {
 extern "C" int babe_cqt_band_analysis(const babe_cqt_bands* bd, const float* spec, const float* win, int B,
                                       void* stream) {
     if (check_bands(bd)) return BABE_ERR_ARG;
-    BABE_CHECK_ARG(spec && win && B > 0, "cqt_band_analysis: bad arguments");
-    BabeProfScope prof(BABE_SLOT_CQT_ANALYSIS, (double)B * (8.0 * (bd->L / 2 + 1) + 8.0 * bd->sum_T + 4.0 * bd->sum_M), 5.0 * B * bd->sum_TlogT, 0, stream);
-    hipLaunchKernelGGL(band_fft_kernel<0>, dim3(bd->nwg, B), dim3(256), 0, (hipStream_t)stream, *bd, spec, (float*)nullptr,
-                       0L, win);
+    BABE_CHECK_ARG(spec && B > 0, "cqt_band_analysis: bad arguments");
+    BABE_CHECK_ARG(win || (bd->kdeg > 0 && bd->kdeg <= 11), "cqt_band_analysis: no window table and no analytic window (kdeg = %d)", bd->kdeg);
+    BabeProfScope prof(BABE_SLOT_CQT_ANALYSIS, (double)B * (8.0 * (bd->L / 2 + 1) + 8.0 * bd->sum_T + (win ? 4.0 : 0.0) * bd->sum_M), 5.0 * B * bd->sum_TlogT, 0, stream);
+    const dim3 grid(bd->nwg, B);
+    const hipStream_t st = (hipStream_t)stream;
+    if (win && B >= 8) hipLaunchKernelGGL((band_fft_kernel<0, false, true>), grid, dim3(256), 0, st, *bd, spec, (float*)nullptr, 0L, win);
+    else if (win) hipLaunchKernelGGL((band_fft_kernel<0, false, false>), grid, dim3(256), 0, st, *bd, spec, (float*)nullptr, 0L, win);
+    else if (B >= 8) hipLaunchKernelGGL((band_fft_kernel<0, true, true>), grid, dim3(256), 0, st, *bd, spec, (float*)nullptr, 0L, win);
+    else hipLaunchKernelGGL((band_fft_kernel<0, true, false>), grid, dim3(256), 0, st, *bd, spec, (float*)nullptr, 0L, win);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }
@@ -564,10 +640,11 @@ extern "C" int babe_cqt_band_analysis(const babe_cqt_bands* bd, const float* spe
 extern "C" int babe_cqt_band_synthesis(const babe_cqt_bands* bd, float* bs, const float* win, long bs_stride, int B,
                                        void* stream) {
     if (check_bands(bd)) return BABE_ERR_ARG;
-    BABE_CHECK_ARG(bs && win && B > 0, "cqt_band_synthesis: bad arguments");
-    BabeProfScope prof(BABE_SLOT_CQT_SYNTHESIS, (double)B * (8.0 * bd->sum_T + 12.0 * bd->sum_M), 5.0 * B * bd->sum_TlogT, 0, stream);
-    hipLaunchKernelGGL(band_fft_kernel<1>, dim3(bd->nwg, B), dim3(256), 0, (hipStream_t)stream, *bd, (const float*)nullptr,
-                       bs, bs_stride, win);
+    BABE_CHECK_ARG(bs && B > 0, "cqt_band_synthesis: bad arguments");
+    BABE_CHECK_ARG(win || (bd->kdeg > 0 && bd->kdeg <= 11), "cqt_band_synthesis: no window table and no analytic window (kdeg = %d)", bd->kdeg);
+    BabeProfScope prof(BABE_SLOT_CQT_SYNTHESIS, (double)B * (8.0 * bd->sum_T + (win ? 12.0 : 8.0) * bd->sum_M), 5.0 * B * bd->sum_TlogT, 0, stream);
+    if (win) hipLaunchKernelGGL((band_fft_kernel<1, false, false>), dim3(bd->nwg, B), dim3(256), 0, (hipStream_t)stream, *bd, (const float*)nullptr, bs, bs_stride, win);
+    else hipLaunchKernelGGL((band_fft_kernel<1, true, false>), dim3(bd->nwg, B), dim3(256), 0, (hipStream_t)stream, *bd, (const float*)nullptr, bs, bs_stride, win);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

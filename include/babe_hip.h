@@ -272,12 +272,19 @@ typedef struct {
     int max_wg_count, min_log2T, max_log2T;
     long sum_T, sum_M;   /* sum over bands of T_k and M_k (for the measurement hook's algorithmic bytes) */
     double sum_TlogT;    /* sum over bands of T_k*log2(T_k) (algorithmic FFT flops = 5*that)            */
+    /* Analytic Kaiser window (round 6): with win == NULL the band kernels evaluate the window g_k(m) / T_k themselves,
+     * g_k(m) = I0(beta sqrt(a)) / I0(beta), a = 1 - (2 m / M_k)^2, as the polynomial sum_j kpoly[j] a^j, j <= kdeg
+     * (kpoly[j] = (beta^2/4)^j / (j!)^2 / I0(beta): the power series of I0, truncated below 1e-9) - the table read was
+     * 4 bytes per point and clip, 6 of the 45 us of the analysis launch at 32 clips.  kdeg = 0: not available (large
+     * beta), the table has to be passed. */
+    int kdeg; float kpoly[12];
 } babe_cqt_bands;
 /* analysis-type: coef_k = IFFT_T(fold(spec[(c_k+m) mod L] * win[woff_k+m']))  (win carries 1/T and any scale).
- * Used for CQT.fwd (win = g/T) and for the adjoint of CQT.bwd (win = (2/L) T^2 gd). */
+ * Used for CQT.fwd (win = g/T, or NULL: evaluated analytically, bands->kdeg > 0) and for the adjoint of CQT.bwd
+ * (win = (2/L) T^2 gd). */
 int babe_cqt_band_analysis(const babe_cqt_bands* bands, const float* spec, const float* win, int B, void* stream);
 /* synthesis-type: bs[b][woff_k+m'] = FFT_T(coef_k)[m mod T] * win[woff_k+m']  (float2).
- * Used for CQT.bwd (win = T gd) and for the adjoint of CQT.fwd (win = g/T). */
+ * Used for CQT.bwd (win = T gd) and for the adjoint of CQT.fwd (win = g/T, or NULL: analytic). */
 int babe_cqt_band_synthesis(const babe_cqt_bands* bands, float* bs, const float* win, long bs_stride, int B,
                             void* stream);
 /* spec[b][:, n] = scale * sum over CSR entries of n of bs (conjugated when the entry's sign bit is set);
@@ -290,6 +297,32 @@ int babe_cqt_gather(const float* bs, long bs_stride, const int* rowptr, const in
  * optional second term: spec_out += spec2 * mul[n] * scale2. */
 int babe_spec_scale(const float* spec_in, const float* spec2, float* spec_out, const float* mul, int KX, int L,
                     float scale, float scale2, int B, void* stream);
+
+/* ---- the whole constant-Q transform from a plan handle (csrc/cqt_plan.hip, round 6): what a non-Python host binds instead of
+ * cqt_nsgt_pytorch.CQT_nsgt(numocts, binsoct, mode="oct", window=("kaiser", beta), fs, audio_len) - constructed at
+ * networks/cqtdiff+.py:620, .fwd :743, .bwd :841, .apply_hpf_DC testing/blind_bwe_sampler.py:156.  The band design (NSGT LogScale
+ * grid, band lengths, Kaiser windows, painless-case dual frame incl. the mirrored bands, power-of-two rasterisation per octave,
+ * the CSR of the overlap-add, the mixed-radix plan of the length-L real FFT) is computed by the library in float64 with the
+ * arithmetic of babe_amd/cqt.py::design_bands (integer tables equal, float tables to a few ulp: tests/test_cqt_plan_cpu.py).
+ *   design: host only, no GPU call.  babe_cqt_design_get copies table `name` (int64: M c T woff idx rowptr src; float64: f Om g
+ *   gdual Tw hpf kpoly; int32: rad1 rad2 wg_first wg_count T_oct; one int64: nb nwin M_dc N1 N2 K2 KX kdeg) into out and returns
+ *   its size in bytes (out = NULL: size only), -1 for an unknown name.
+ *   plan: design + device tables (one allocation on the current device).  Coefficients are planar, one tensor per octave:
+ *   coef[j] = [B][2][binsoct][T_oct[j]], j = 0 the LOWEST octave (the [B,2,64,T] tensors the UNet consumes).  ws: device scratch of
+ *   babe_cqt_workspace_bytes(plan, B) bytes, owned by the caller (one per concurrent stream).  NULL / negative on failure
+ *   (babe_last_error()). */
+void* babe_cqt_design_create(double fs, int audio_len, int numocts, int binsoct, double beta);
+void babe_cqt_design_destroy(void* design);
+long babe_cqt_design_get(const void* design, const char* name, void* out, long capacity_bytes);
+void* babe_cqt_plan_create(double fs, int audio_len, int numocts, int binsoct, double beta);
+void babe_cqt_plan_destroy(void* plan);
+const void* babe_cqt_plan_design(const void* plan);                  /* the plan's design (owned by the plan), for babe_cqt_design_get */
+long babe_cqt_workspace_bytes(const void* plan, int B);
+int babe_cqt_fwd(const void* plan, const float* x, float* const* coef, float* ws, int B, void* stream);            /* .fwd: x [B][L] -> coef */
+int babe_cqt_bwd(const void* plan, float* const* coef, float* x, float* ws, int B, void* stream);                  /* .bwd: coef -> x [B][L] */
+int babe_cqt_fwd_adjoint(const void* plan, float* const* gcoef, float* gx, float* ws, int B, void* stream);        /* (.fwd)^T, for the VJP */
+int babe_cqt_bwd_adjoint(const void* plan, const float* gx, float* const* gcoef, float* ws, int B, void* stream);  /* (.bwd)^T, for the VJP */
+int babe_cqt_hpf(const void* plan, const float* x, float* out, float* ws, int B, void* stream);                    /* .apply_hpf_DC (self-adjoint) */
 
 /* ---- STFT-domain degradation model: utils/blind_bwe_utils.py:6-39 (apply_stft / apply_filter_istft /
  * apply_filter) and testing/blind_bwe_sampler.py:518-595.  nfft in {256..4096} (power of two), hop nfft/2,

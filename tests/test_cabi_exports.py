@@ -43,6 +43,44 @@ def test_unet_plan_structs_have_the_headers_layout(tmp_path):
     assert got == want, (got, want)
 
 
+def test_cqt_bands_struct_has_the_headers_layout(tmp_path):
+    """babe_amd/cqt.py mirrors babe_cqt_bands with ctypes (passed BY VALUE to the band kernels): size and the offsets of the
+    fields round 6 appended (analytic Kaiser window) must be the header's."""
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    from babe_amd.cqt import _BandsStruct
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n",'
+                   ' sizeof(babe_cqt_bands), offsetof(babe_cqt_bands, coef), offsetof(babe_cqt_bands, wg_rec), offsetof(babe_cqt_bands, sum_T),'
+                   ' offsetof(babe_cqt_bands, kdeg), offsetof(babe_cqt_bands, kpoly));return 0;}\n'
+                   % os.path.join(ROOT, "include", "babe_hip.h"))
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    want = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    got = [ctypes.sizeof(_BandsStruct), _BandsStruct.coef.offset, _BandsStruct.wg_rec.offset, _BandsStruct.sum_T.offset,
+           _BandsStruct.kdeg.offset, _BandsStruct.kpoly.offset]
+    assert got == want, (got, want)
+
+
+def test_kaiser_poly_reproduces_the_window_table():
+    """The truncated I0 series the band kernels evaluate (babe_cqt_bands::kpoly) against the float64 Kaiser window the tables
+    are built from: below fp32 resolution for the betas it accepts; large betas fall back to the table."""
+    import numpy as np
+    from babe_amd.cqt import _kaiser, kaiser_poly
+    for beta in (0.5, 1.0, 2.0, 3.0):
+        deg, co = kaiser_poly(beta)
+        assert 1 <= deg <= 11 and (co[deg + 1:] == 0).all()
+        for M in (4, 7, 64, 1001, 4096):
+            m = np.arange(-(M // 2), M - M // 2)
+            a = np.maximum(1 - (2.0 * m / M) ** 2, 0)
+            p = sum(co[j] * a ** j for j in range(12))
+            assert np.abs(p - _kaiser(M, beta)).max() < 3e-9
+    assert kaiser_poly(8.6) is None
+
+
 def test_unet_plan_create_validates_every_block():
     """babe_unet_plan_create takes descriptors from any C-ABI host: a dilation-layer count outside 0..8 (it indexes saved[..][8],
     H[8], gamma[8]), a channel count that is not a positive multiple of the 8 GroupNorm groups, or a missing gamma / packed image

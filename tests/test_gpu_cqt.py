@@ -131,3 +131,31 @@ def test_length_L_fft_and_transpose_other_lengths(L):
     print(f"L={L}: N1 x N2 = {fft.N1} x {fft.N2}, mixed-radix {fft.mixed} ({getattr(fft, 'rad1', None)} / {getattr(fft, 'rad2', None)}), rfft err {err:.1e}")
     assert err < 5e-6
     assert abs(lhs - rhs) < 2e-5 * (abs(lhs) + abs(rhs) + 1e3)
+
+
+@pytest.mark.parametrize("fs,L", [(22050, 92092), (44100, 368368), (16000, 184184)])
+def test_library_plan_equals_the_python_sequenced_transform(fs, L, monkeypatch):
+    """csrc/cqt_plan.hip (band design in C++, device tables, one C call per transform: babe_cqt_fwd / _bwd / _fwd_adjoint /
+    _bwd_adjoint / _hpf) against this class sequencing the same kernels from the numpy design.  The two designs agree to a few
+    float64 ulp (tests/test_cqt_plan_cpu.py), i.e. a 1-ulp float32 difference in < 1e-4 of the table entries: bar 1e-6 relative;
+    fwd reads no table (analytic window) and must be bit-identical."""
+    from babe_amd.cqt import CQT_nsgt
+    py = CQT_nsgt(7, 64, "oct", ("kaiser", 1), fs, L, device="cuda")
+    monkeypatch.setenv("BABE_CQT_C", "1")
+    cc = CQT_nsgt(7, 64, "oct", ("kaiser", 1), fs, L, device="cuda")
+    monkeypatch.delenv("BABE_CQT_C")
+    assert cc._plan and not py._plan
+    g = torch.Generator().manual_seed(11)
+    for B in (1, 3):
+        x = (0.1 * torch.randn(B, L, generator=g)).cuda()
+        c_py, c_cc = py.fwd_planar(x), cc.fwd_planar(x)
+        assert all(torch.equal(a, b) for a, b in zip(c_py, c_cc)), "fwd: analytic window, same kernels, same order"
+        gco = [torch.randn(c.shape, generator=g).cuda() for c in c_py]
+        assert rel(cc.bwd_planar(gco), py.bwd_planar(gco)) < 1e-6
+        assert rel(cc.fwd_adjoint(gco), py.fwd_adjoint(gco)) < 1e-6
+        for a, b in zip(cc.bwd_adjoint(x), py.bwd_adjoint(x)):
+            assert rel(a, b) < 1e-6
+        assert rel(cc.apply_hpf_DC(x), py.apply_hpf_DC(x)) < 1e-6
+    # and the reference API on top of the plan: bwd(fwd(x)) = apply_hpf_DC(x)
+    x = (0.1 * torch.randn(2, 1, L, generator=g)).cuda()
+    assert rel(cc.bwd(cc.fwd(x)).squeeze(1), cc.apply_hpf_DC(x.squeeze(1))) < 5e-5

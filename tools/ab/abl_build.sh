@@ -2,7 +2,7 @@
 # usage: abl_build.sh <file-stem> <n>...   builds tools/abl_out/abl<n>/libbabe_hip.so with -DABL=n for csrc/<stem>.hip
 # (same compile flags as the product build: babe_amd.build.COMMON_FLAGS - no packed-fp32 instructions)
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 stem=$1; shift
 flags=$(python3 -c "import babe_amd.build as b; print(' '.join(b.COMMON_FLAGS + b.EXTRA_FLAGS.get('$stem.hip', [])))")
 for n in "$@"; do
