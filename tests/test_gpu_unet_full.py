@@ -260,3 +260,90 @@ def test_full_width_bf16_sampler_B4_per_clip_vs_fp32_reference_runs(monkeypatch)
     # packed-fp32 instructions, babe_amd/build.py, two-lane bf16 runs differed about one time in four)
     assert net.concurrent_lanes_ok and smp._use_lanes(4, y, False, fp.reshape(4, 2, -1))
     assert torch.equal(x[0], x[2]) and torch.equal(x[1], x[3])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6: the BENCHMARKED composition at its real size - full width, L = 368368, 44.1 kHz, network UNWRAPPED, the F(4,5) x F(4,3)
+# kernels inside the sampler loop - against the imported reference (tests/golden/make_golden.py::g24)
+
+def _noises_full(s, B):
+    L, T = int(s["L"]), int(s["T"])
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    torch.randn(L, generator=gen)                                            # the draw that made the observation (synth_obs)
+    return [torch.randn(1, L, generator=gen).repeat(B, 1) for _ in range(T + 1)]
+
+
+def _full_size_sampler(net, s):
+    from babe_amd.config import default_args
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    L, T = int(s["L"]), int(s["T"])
+    args = default_args(sample_rate=44100, audio_len=L, T=T, start_sigma=float(s["start_sigma"]))
+    args.tester.blind_bwe.optimization.mu = [float(v) for v in s["mu"]]
+    return BlindSampler(net, EDM(args), args, batch_semantics="per_clip")
+
+
+def test_full_size_blind_sampler_two_lanes_vs_reference_golden():
+    """predict_blind_bwe (testing/blind_bwe_sampler.py:619-769) exactly as bench.py runs it - full width, 368368-sample segment,
+    two stream lanes, default conv dispatch (the nested F(4,5) x F(4,3) kernels), fast fit kernel - against the imported
+    reference's own run: T = 2 from sigma 0.2 = 3 score evaluations, network unwrapped, so UNet error reaches the output
+    unattenuated.  The golden's conditioning is stored with it: a 1e-6 relative perturbation of y moves the REFERENCE's output
+    by `probe_moved_x` (1.4e-4), which is what two correct fp32 implementations may differ by.  Bars: output RMS error < 1e-3
+    (north star), per-step denoised estimate < 1e-3 relative, filter within params_close."""
+    from babe_amd._lib import dispatch_counts
+    s = load("sampler_full_368368.npz")
+    L, T = int(s["L"]), int(s["T"])
+    net = full_net(L)
+    smp = _full_size_sampler(net, s)
+    assert smp.LANES == 2
+    print(f"golden: mu = {s['mu'].tolist()}, 1e-6 perturbation of y moves the reference's x by {float(s['probe_moved_x']):.2e}, the filter by {float(s['probe_moved_fp']):.2e}")
+    # per-step records (B = 1, rid=True: single-stream loop)
+    it = iter(_noises_full(s, 1))
+    smp._randn = lambda shape, device: next(it).to(device)
+    dispatch_counts(reset=True)
+    x1, fp1, den, tt, filt = smp.predict_blind_bwe(s["y"].cuda(), rid=True)
+    torch.cuda.synchronize()
+    cnt1 = dispatch_counts(reset=True)
+    assert torch.equal(tt, s["t"])
+    for i in range(T):
+        e = rel(den[i][:, ::16], s["data_denoised_sub16"][i])
+        print(f"  step {i}: x_den rel {e:.2e}, filter {filt[i].tolist()} vs {s['data_filters'][i].tolist()}")
+        assert e < 1e-3, (i, e)
+        assert torch.allclose(filt[i][0], s["data_filters"][i][0], rtol=1e-2) and torch.allclose(filt[i][1], s["data_filters"][i][1], atol=1.0)
+    print(f"  B = 1 single stream: RMS err {rms_err(x1, s['x']):.2e}, rel {rel(x1, s['x']):.2e}")
+    assert rms_err(x1, s["x"]) < 1e-3 and rel(x1, s["x"]) < 5e-3
+    assert cnt1["conv53_wino85"] >= 3 * 142, cnt1
+    # both lanes: the clip twice as one per-clip batch on two streams - what bench.py times
+    y2 = s["y"].repeat(2, 1).cuda()
+    it = iter(_noises_full(s, 2))
+    smp._randn = lambda shape, device: next(it).to(device)
+    x, fp = smp.predict_blind_bwe(y2)
+    torch.cuda.synchronize()
+    cnt = dispatch_counts(reset=True)
+    assert smp._use_lanes(2, y2, False, fp)
+    print("full-size sampler dispatch (two lanes):", {k: v for k, v in cnt.items() if v})
+    assert cnt["conv53_wino85"] >= 2 * 3 * 142 and cnt["conv_bf16"] == 0 and cnt["conv53_direct"] == 0, cnt
+    for b in range(2):
+        e_rms, e_rel = rms_err(x[b:b + 1], s["x"]), rel(x[b:b + 1], s["x"])
+        print(f"full-size sampler lane {b}: RMS err {e_rms:.2e}, rel {e_rel:.2e}; filter {fp[b].tolist()} vs {s['filter_params'].tolist()}")
+        assert e_rms < 1e-3 and e_rel < 5e-3
+        assert torch.allclose(fp[b, 0].cpu(), s["filter_params"][0], rtol=1e-2) and torch.allclose(fp[b, 1].cpu(), s["filter_params"][1], atol=1.0)
+    assert torch.equal(x[0], x[1])                                           # same clip, same noise: bit-identical lanes
+
+
+def test_full_size_blind_sampler_bf16_bar():
+    """The same golden at a bf16 bar (configs[2]'s arithmetic; the T = 3 goldens wrap the network and attenuate UNet error ~1000x,
+    this one does not): output RMS error < 5e-3 (signal RMS ~0.1), per-step x_den < 5e-2 relative."""
+    s = load("sampler_full_368368.npz")
+    L, T = int(s["L"]), int(s["T"])
+    net = full_net(L, "bf16")
+    smp = _full_size_sampler(net, s)
+    it = iter(_noises_full(s, 1))
+    smp._randn = lambda shape, device: next(it).to(device)
+    x, fp, den, tt, filt = smp.predict_blind_bwe(s["y"].cuda(), rid=True)
+    for i in range(T):
+        e = rel(den[i][:, ::16], s["data_denoised_sub16"][i])
+        print(f"  bf16 step {i}: x_den rel {e:.2e}")
+        assert e < 5e-2
+    print(f"full-size bf16 sampler: RMS err {rms_err(x, s['x']):.2e}, rel {rel(x, s['x']):.2e}")
+    assert rms_err(x, s["x"]) < 5e-3

@@ -9,6 +9,27 @@ from babe_amd.cqt import CQT_nsgt
 L, fs = 368368, 44100
 cq = CQT_nsgt(7, 64, "oct", ("kaiser", 1), fs, L, device="cuda")
 ncoef = sum(64 * T for T in cq.T_oct)
+
+
+def event_bracket_floor():
+    """What the HIP-event bracket of the measurement hook reads for a kernel that does (almost) nothing: one 256-thread workgroup
+    of babe_spec_scale.  The bracket [event, launch, event] contains the dispatch latency between the first event's timestamp and
+    the kernel's start; a rocprofv3 kernel trace (tools/cqt_trace_summary.py) reports the kernel's own begin / end."""
+    t = torch.zeros(1, 2, 256, device="cuda")
+    m = torch.ones(256, device="cuda")
+    from babe_amd._lib import check, lib, ptr, stream
+    _lib.prof_read()
+    _lib.prof_enable(True)
+    for _ in range(50):
+        check(lib().babe_spec_scale(ptr(t), None, ptr(t), ptr(m), 256, 2, 1.0, 0.0, 1, stream()), "spec_scale")
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    pr = _lib.prof_read()["cqt_gather"]
+    return pr["ms"] * 1e3 / max(pr["launches"], 1)
+
+
+print(f"# HIP-event bracket of a one-workgroup kernel (the floor every [GPU time, HIP events] figure below contains): {event_bracket_floor():.1f} us; "
+      f"kernel-only durations: tools/cqt_trace_summary.py over a rocprofv3 --kernel-trace of this script")
 for B in [int(v) for v in os.environ.get("BS", "1,2,8,32,64").split(",")]:
     x = torch.randn(B, L, device="cuda")
     spec = cq.fft.rfft(x)
