@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libbabe_hip.so")
-SOURCES = ["misc.hip", "conv.hip", "conv11p.hip", "conv_fewco.hip", "conv_bf16.hip", "conv_bf16p.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4p.hip", "conv_wino45.hip", "conv_wino85.hip", "norm.hip", "resample.hip", "resample_sinc.hip", "cqt.hip", "cqt_plan.hip", "fft_mixed.hip", "unet_engine.hip", "stft.hip", "sampler.hip", "denoiser.hip"]
+SOURCES = ["misc.hip", "conv.hip", "conv11p.hip", "conv_fewco.hip", "conv_bf16.hip", "conv_bf16p.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4p.hip", "conv_wino45.hip", "conv_wino85.hip", "norm.hip", "resample.hip", "resample_sinc.hip", "cqt.hip", "cqt_plan.hip", "fft_mixed.hip", "unet_engine.hip", "score_eval.hip", "stft.hip", "sampler.hip", "denoiser.hip"]
 
 
 # Every source is built WITHOUT packed-fp32 instructions: no SLP vectoriser (-fno-slp-vectorize) and the target feature

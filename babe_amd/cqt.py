@@ -302,6 +302,7 @@ class CQT_nsgt:
         self.Ls, self.fs, self.numocts, self.binsoct = int(audio_len), fs, numocts, binsoct
         self.device = torch.device(device)
         d = design_bands(fs, self.Ls, numocts, binsoct, float(window[1]))
+        d["beta"] = float(window[1])
         self.design = d
         L = self.Ls
         dev = self.device

@@ -26,6 +26,10 @@ import torch
 from ..stft import STFTOps, add_obs_noise, fir_same, lincomb, make_fit_cfg, mask_blend
 from .._lib import check, lib, ptr, stream
 
+# BABE_EVAL_C=1: every score evaluation of the default configuration is ONE library call (csrc/score_eval.hip through
+# testing/eval_c.py: the non-Python host's path); default: this class sequences the kernels itself
+EVAL_C = os.environ.get("BABE_EVAL_C", "0") == "1"
+
 
 class BlindSampler:
     NBLK = 64
@@ -90,6 +94,7 @@ class BlindSampler:
                                     only_negative_A=bb.optimization.only_negative_A,
                                     weighting=ps.freq_weighting_filter)
         self._stft = None
+        self._ceval = {}               # BABE_EVAL_C=1: one library-side evaluation descriptor per lane (testing/eval_c.py)
         self.fir_taps = None
         self.ar_mask = None            # predict_bwe_AR: degradation(x) = mask*x + (1-mask)*A(x)
         self.dc = None                 # (smooth_mask, y_smooth_masked) of the replacement data-consistency step
@@ -164,6 +169,13 @@ class BlindSampler:
         st = self._stft
         cq = self.model.CQTransform
         B, L = x.shape
+        if EVAL_C:
+            from . import eval_c
+            if eval_c.supported(self, y, blind) and x.is_contiguous() and y.is_contiguous():
+                ce = self._ceval.get(lane)
+                if ce is None or ce._keep[1] is not st:
+                    ce = self._ceval[lane] = eval_c.CEval(self, lane)
+                return ce(self, x, t, y, specY, filter_params, blind)
         x_den = self.get_denoised_estimate(x, t, lane)
         cskip, cout, cin = self._c
         specX_fit = None

@@ -407,6 +407,37 @@ int babe_score_direction(const float* xden, const float* xhat, const float* g, c
                          float* d, float t, float xi, float audio_len, int shared_norm, int mode, int B, long n,
                          void* stream);
 
+/* ---- one whole SCORE EVALUATION from plan handles (csrc/score_eval.hip, round 6): what BlindSampler.evaluate sequences from
+ * Python (testing/blind_bwe_sampler.py:75-170, 503-595, 687-761; diff_params/edm.py:144-159), as one call for a non-Python host:
+ * preconditioned denoiser (CQT.fwd -> UNet -> CQT.bwd) -> apply_hpf_DC -> STFT -> [filter fit] -> filter design -> residual
+ * y - A(x_den) and the gradient of its norm through iSTFT o H o STFT, the high-pass and the network -> score direction.
+ * Default configuration only (L2 guidance norm, STFT-domain low-pass, no observation noise / data-consistency / AR mask / FIR);
+ * bit-identical to the Python sequencer on it (tests/test_gpu_eval_c.py).  No allocation, no synchronisation. */
+typedef struct {
+    const void* unet_plan; void* unet_state;      /* babe_unet_plan_create / babe_unet_state_create (one state per stream) */
+    const void* cqt_plan;                         /* babe_cqt_plan_create for (fs, L) */
+    int L;                                        /* exp.audio_len */
+    /* noise embedding (RFF_MLP_Block cqtdiff+.py:184-211) and every FiLM Linear (:36-40) stacked into one matrix */
+    const float* rff_freq; int rff_n;             /* embedding.RFF_freq [rff_n] */
+    const float* emb_W[3]; const float* emb_b[3]; /* embedding.MLP.i weight [emb_dim[i+1]][emb_dim[i]], bias */
+    int emb_dim[4];                               /* emb_dim[0] = 2 * rff_n */
+    const float* film_W; const float* film_b; int film_J;   /* [film_J][emb_dim[3]]: affine / gate rows in the UNet plan's order */
+    /* STFT-domain degradation model (utils/blind_bwe_utils.py): nfft, periodic-Hamming OLA envelope 1 / sum w^2
+     * [nfft + hop (frames - 1)], exp(-2 pi i q / 4096) [2048] float2 */
+    int nfft; float fs; const float* env_inv; const float* tw4096;
+    int K;                                        /* break points of the piecewise filter (<= 8) */
+    babe_fit_cfg fit;
+    int blind;                                    /* 1: fit the filter parameters in this evaluation (predict_blind_bwe) */
+    int shared;                                   /* 1: the reference's batch coupling (one filter, whole-batch norms); 0: per clip */
+    int hpf;                                      /* tester.filter_out_cqt_DC_Nyq */
+    float xi; int score_mode; float audio_len_norm;   /* babe_score_direction's xi, mode and audio_len */
+} babe_eval_desc;
+long babe_eval_workspace_bytes(const babe_eval_desc* desc, int B);
+int babe_score_eval(const babe_eval_desc* desc, const float* x, float t, float cskip, float cout, float cin, float cnoise,
+                    const float* y, const float* specY, float* params, float* d, float* x_den, int* n_iter, void* ws,
+                    long ws_bytes, int B, void* stream);
+int babe_fill(float* out, float v, int n, void* stream);            /* out[0..n) = v (the [B][1] cnoise input of the embedding) */
+
 /* ---- Denoiser pre-pass: networks/denoiser.py:232-321 (MultiStage_denoise, inference only) and
  * testing/denoise_and_bwe_tester.py:146-165 (STFT 1024/256 -> network -> inverse STFT).  csrc/denoiser.hip --------- */
 /* General small-kernel Conv2d on [B][C][H][W] tensors with contiguous rows (replaces nn.Conv2d with
