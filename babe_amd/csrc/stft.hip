@@ -283,17 +283,20 @@ __device__ __forceinline__ float weight_sq(int k, int nbins, int kind) {
 }
 
 // one block per clip
+// lossgrad != NULL: no descent - the loss and its gradient at `params` are written ([P][1 + 2K]: loss, d/dfc_j, d/dA_j) and the
+// parameters are left alone (BlindSampler.compute_sweep, testing/blind_bwe_sampler.py:598-616); stats_ps: stride between the
+// statistics of consecutive parameter sets, in doubles (0: one set of statistics for all of them)
 __global__ __launch_bounds__(256) void filter_fit_kernel(const double* __restrict__ stats, float* __restrict__ params,
                                                          int* __restrict__ n_iter, int K, int nbins, float df,
-                                                         babe_fit_cfg cfg) {
+                                                         babe_fit_cfg cfg, long stats_ps, float* __restrict__ lossgrad) {
     __shared__ Filt F;
     __shared__ double red[4][2 * KMAX + 1];
     __shared__ float prev[2 * KMAX];
     __shared__ int done;
     const int p = blockIdx.x;
-    const double* Sxx = stats + ((long)p * 3 + 0) * nbins;
-    const double* Sxy = stats + ((long)p * 3 + 1) * nbins;
-    const double* Syy = stats + ((long)p * 3 + 2) * nbins;
+    const double* Sxx = stats + (long)p * stats_ps;
+    const double* Sxy = Sxx + nbins;
+    const double* Syy = Sxx + 2 * nbins;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
         for (int i = 0; i < K; ++i) {
@@ -372,6 +375,14 @@ __global__ __launch_bounds__(256) void filter_fit_kernel(const double* __restric
                 const double gfc = -(double)F.A[j] / ((double)F.fc[j] * 0.6931471805599453) * suf[j] * il;
                 nfc[j] = F.fc[j] - cfg.mu_fc * (float)gfc;
                 nA[j] = F.A[j] - cfg.mu_A * (float)gA;
+                if (lossgrad) {
+                    lossgrad[(long)p * (1 + 2 * K) + 1 + j] = (float)gfc;
+                    lossgrad[(long)p * (1 + 2 * K) + 1 + K + j] = (float)gA;
+                }
+            }
+            if (lossgrad) {
+                lossgrad[(long)p * (1 + 2 * K)] = (float)loss;
+                done = 2;                                      // (evaluation only: parameters untouched)
             }
             if (cfg.clamp_fc) {
                 nfc[0] = fminf(fmaxf(nfc[0], cfg.fcmin), cfg.fcmax);
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(256) void filter_fit_kernel(const double* __restric
                 }
                 if (dfc / K < cfg.tol_fc && dA / K < cfg.tol_A) done = 1;
             }
-            for (int j = 0; j < K; ++j) {
+            for (int j = 0; j < K && done != 2; ++j) {
                 F.fc[j] = nfc[j];
                 F.A[j] = nA[j];
                 prev[j] = nfc[j];
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(256) void filter_fit_kernel(const double* __restric
             break;
         }
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !lossgrad) {
         for (int i = 0; i < K; ++i) {
             params[((long)p * 2 + 0) * K + i] = F.fc[i];
             params[((long)p * 2 + 1) * K + i] = F.A[i];
@@ -790,7 +801,20 @@ extern "C" int babe_filter_fit(const double* stats, float* params, int* n_iter, 
 #undef FIT_CASE
     } else
         hipLaunchKernelGGL(filter_fit_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, stats, params, n_iter, K, nbins,
-                           df, *cfg);
+                           df, *cfg, 3L * nbins, (float*)nullptr);
+    BABE_LAUNCH_CHECK();
+    return BABE_OK;
+}
+
+extern "C" int babe_filter_loss_grad(const double* stats, long stats_pstride, const float* params, float* lossgrad, int P, int K,
+                                     int nbins, float fs, int nfft, const babe_fit_cfg* cfg, void* stream) {
+    BABE_CHECK_ARG(stats && params && lossgrad && cfg && P > 0 && K > 0 && K <= KMAX && nbins > 1 && stats_pstride >= 0,
+                   "filter_loss_grad: bad arguments");
+    BabeProfScope prof(BABE_SLOT_FILTER_FIT, 24.0 * P * (double)nbins, 0, 0, stream);
+    babe_fit_cfg c = *cfg;
+    c.max_iter = 1;
+    hipLaunchKernelGGL(filter_fit_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, stats, const_cast<float*>(params),
+                       (int*)nullptr, K, nbins, fs / (float)nfft, c, stats_pstride, lossgrad);
     BABE_LAUNCH_CHECK();
     return BABE_OK;
 }

@@ -40,6 +40,7 @@ def _register():
         "babe_stft_mag_stats": [P, P, P, I, I, I, I, P],
         "babe_design_filter": [P, P, I, I, I, F, I, P],
         "babe_filter_fit": [P, P, P, I, I, I, F, I, C.POINTER(FitCfg), P],
+        "babe_filter_loss_grad": [P, Lg, P, P, I, I, I, F, I, C.POINTER(FitCfg), P],
         "babe_lincomb3": [P, F, P, F, P, F, P, Lg, P],
         "babe_add_obs_noise": [P, Lg, P, Lg, F, I, Lg, P],
         "babe_sumsq_partial": [P, Lg, P, I, I, Lg, P],
@@ -204,6 +205,17 @@ class STFTOps:
         check(lib().babe_filter_fit(ptr(stats), ptr(params), ptr(nit), P_, K, self.nbins, self.fs, self.nfft,
                                     C.byref(cfg), stream()), "filter_fit")
         return nit
+
+    def filter_loss_grad(self, stats, params, cfg):
+        """The fit's objective and its gradient at params [P,2,K] WITHOUT a descent step (BlindSampler.optimizer_func + autograd,
+        as compute_sweep evaluates them on a grid): returns [P, 1 + 2K] = loss, d/dfc_j, d/dA_j.  stats [P,3,nbins], or [1,3,nbins]
+        shared by all P parameter sets."""
+        P_, _, K = params.shape
+        assert params.is_contiguous() and stats.shape[0] in (1, P_)
+        out = torch.empty(P_, 1 + 2 * K, device=self.dev)
+        check(lib().babe_filter_loss_grad(ptr(stats), 0 if (stats.shape[0] == 1 and P_ > 1) else 3 * self.nbins, ptr(params), ptr(out),
+                                          P_, K, self.nbins, self.fs, self.nfft, C.byref(cfg), stream()), "filter_loss_grad")
+        return out
 
     def distance_grad(self, rec, y, weight, mode, shared=False):
         """d D(y, rec) / d rec for the STFT-domain guidance distances (get_rec_grads :105-115): mode 0 complex, 1 magnitude,

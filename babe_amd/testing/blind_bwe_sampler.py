@@ -215,6 +215,11 @@ class BlindSampler:
                 u = mask_blend(m, None, self._seed(st, r, y, part, post=True))
                 gA = st.ola(st.filter_frames(st.stft(u), Hq), normalise=False)
             g_den = lincomb(torch.empty_like(gA), 1.0, mask_blend(m, seed_raw, None), 1.0, gA)
+        elif getattr(self, "inpaint_mask", None) is not None:
+            # masking degradation of edm_sampler.Sampler.predict_inpainting (edm_sampler.py:231-243): A(x) = mask * x, self-adjoint
+            m = self.inpaint_mask
+            r = lincomb(torch.empty_like(y), 1.0, y, -1.0, mask_blend(m, x_den, None))
+            g_den = mask_blend(m, self._seed(st, r, y, self._sumsq(r), post=False), None)
         elif self.fir_taps is not None:
             # known FIR degradation (edm_sampler.py:245-252): residual, then the transpose FIR
             rec = fir_same(x_den, self.fir_taps)
@@ -253,7 +258,9 @@ class BlindSampler:
             # posterior_sampling.data_consistency (conf/tester/blind_bwe_DC.yaml, bwe_formal_1000_DC.yaml): the classic
             # replacement x0 <- y + x0 - A(x0) with the CURRENT degradation (:63-73; :178-188, :704-709, :748-753)
             x0 = lincomb(torch.empty_like(x), 1.0, x, -float(t), d)
-            if self.fir_taps is not None:
+            if getattr(self, "inpaint_mask", None) is not None:
+                a0 = mask_blend(self.inpaint_mask, x0, None)
+            elif self.fir_taps is not None:
                 a0 = fir_same(x0, self.fir_taps)
             else:
                 H = st.design_filter(filter_params)
@@ -281,8 +288,12 @@ class BlindSampler:
             x = lincomb(torch.empty_like(x), 1.0, x_hat, h, d)
         return x, filter_params, rec
 
-    def _sample(self, y, filter_params, blind, rid, snoise=1.0, shape=None, device=None):
-        """y None: unconditional sampling of `shape` on `device` (predict_unconditional :366-374)."""
+    def _sample(self, y, filter_params, blind, rid, snoise=1.0, shape=None, device=None, diag=(False, False)):
+        """y None: unconditional sampling of `shape` on `device` (predict_unconditional :366-374).
+        diag = (test_filter_fit, compute_sweep): the two diagnostics of the known-degradation loop (predict :419-466) - per step, on
+        the guided Tweedie estimate: a filter fit from the INITIAL conditions (the reference never feeds the estimate back) and
+        the fit objective + gradient on a (fc, A) grid.  They do not touch the trajectory; with rid their records are appended."""
+        test_fit, sweep = diag if (y is not None and not blind) else (False, False)
         dp = self.diff_params
         if y is not None:
             device = y.device
@@ -309,7 +320,14 @@ class BlindSampler:
                 t = dp.create_schedule_from_initial_t(self.start_sigma, T)
                 x = lincomb(torch.empty_like(y), 1.0, y, float(t[0]), self._randn((B, L), device).contiguous())
             gamma = dp.get_gamma(t)
-            if self._use_lanes(B, y, rid, filter_params):
+            if sweep:
+                self.fc_s, self.A_s = torch.logspace(2.5, 4, 15), torch.linspace(-80, -5, 12)      # (:439-440)
+            if rid and test_fit:
+                data_fit = []
+            if rid and sweep:
+                data_norms = torch.zeros((T, 15, 12))
+                data_grads = torch.zeros((T, 15, 12, 2))
+            if self._use_lanes(B, y, rid, filter_params) and not (test_fit or sweep):
                 x, filter_params = self._sample_lanes(x, y, specY, filter_params, blind, snoise, t, gamma)
                 T = 0                                        # (loop below skipped)
             for i in range(T):
@@ -325,10 +343,89 @@ class BlindSampler:
                     th = rec["t_hat"]
                     data_denoised[i] = lincomb(torch.empty_like(x), 1.0, rec["x_hat"], -th, rec["d"]).cpu()
                     data_score[i] = lincomb(torch.empty_like(x), -1.0 / th, rec["d"]).cpu()
+                if test_fit or sweep:
+                    den = lincomb(torch.empty_like(x), 1.0, rec["x_hat"], -rec["t_hat"], rec["d"])       # score2denoised (:452, :456)
+                    if test_fit:
+                        est = self.fit_params_signal(den, y, self._init_params(B, device))
+                        if rid:
+                            data_fit.append((est[0] if est.shape[0] == 1 else est).cpu())
+                    if sweep:
+                        norms, grads = self.compute_sweep(den, y)
+                        if rid:
+                            data_norms[i], data_grads[i] = norms, grads
         if blind:
             fp_out = filter_params[0] if (filter_params.shape[0] == 1) else filter_params
             return (x, fp_out, data_denoised, t, data_filters) if rid else (x, fp_out)
-        return (x, data_denoised, data_score, t) if rid else (x,)
+        if not rid:
+            return (x,)
+        out = (x, data_denoised, data_score, t)
+        if test_fit:
+            out = out + (torch.stack(data_fit),)
+        if sweep:
+            out = out + (data_norms, data_grads)
+        return out
+
+    # ---- the reference's helper methods under their own names and signatures (third-party code that pokes at the sampler)
+    def move_timestep(self, x, t, gamma, Snoise=1):
+        """(:509-516) x_hat = x + sqrt(t_hat^2 - t^2) * Snoise * eps, t_hat = t + gamma t; the noise is drawn here, like there."""
+        t_hat = t + gamma * t
+        eps = self._randn(tuple(x.shape), x.device).contiguous()
+        x_hat = lincomb(torch.empty_like(x), 1.0, x.contiguous(), float((t_hat ** 2 - t ** 2) ** (1 / 2)) * float(Snoise), eps)
+        return x_hat, t_hat
+
+    def apply_filter_fcA(self, x, filter_params):
+        """(:518-520) x [B,L] through the piecewise filter filter_params [2,K]."""
+        st = self.stft_ops(x.shape[-1], x.device)
+        return st.apply_filter(x.contiguous(), st.design_filter(torch.as_tensor(filter_params, dtype=torch.float32, device=x.device)))
+
+    def fit_params_signal(self, denoised_estimate, y, filter_params):
+        """The reference's fit_params(denoised_estimate, y, filter_params) (:533-595) on SIGNALS: both STFTs are taken here.
+        filter_params [2,K] or [P,2,K]; returned in the same form.  (fit_params above takes the spectra - the sampling loop has them.)"""
+        st = self.stft_ops(y.shape[-1], y.device)
+        fp = torch.as_tensor(filter_params, dtype=torch.float32, device=y.device)
+        single = fp.dim() == 2
+        out, self.last_n_iter = self.fit_params(st.stft(denoised_estimate.contiguous()), st.stft(y.contiguous()),
+                                                (fp.unsqueeze(0) if single else fp).contiguous())
+        return out[0] if single else out
+
+    def get_rec_grads(self, x_hat, y, x, t_i, degradation=None, filter_params=None):
+        """(:75-135) s * grad_x ||y - A(x_hat)|| / t_i with s = xi / (||grad|| / sqrt(audio_len) + 1e-6), for x_hat = the estimate
+        the LAST get_denoised_estimate(x, t) call returned: where the reference differentiates through the network with autograd,
+        this runs the network's hand-wired VJP on the state that call left (so it must directly follow it, as in the reference's
+        get_score).  L2 norm and STFT-domain low-pass A = filter_params [2,K] (or the FIR taps set by predict_bwe(..., 'firwin'));
+        `degradation` is accepted for the signature and not called.  The sampling loop does the same inside evaluate()."""
+        if self.norm != 2 or self.stft_dist is not None or self.obs_snr is not None:
+            raise NotImplementedError("get_rec_grads helper: default guidance distance only (the sampling loop handles the others)")
+        st = self.stft_ops(y.shape[-1], y.device)
+        cskip, cout, cin = self._c
+        x_hat, y = x_hat.contiguous(), y.contiguous()
+        if self.fir_taps is not None:
+            r = lincomb(torch.empty_like(y), 1.0, y, -1.0, fir_same(x_hat, self.fir_taps))
+            g_den = fir_same(self._seed(st, r, y, self._sumsq(r), post=False), self.fir_taps, adjoint=True)
+        else:
+            H = st.design_filter(torch.as_tensor(filter_params, dtype=torch.float32, device=y.device))
+            Hq = H[0] if (H.dim() == 2 and H.shape[0] != x_hat.shape[0]) else H
+            r, part = st.ola(st.filter_frames(st.stft(x_hat), Hq), normalise=True, y=y)
+            g_den = st.ola(st.filter_frames(st.stft(self._seed(st, r, y, part, post=True)), Hq), normalise=False)
+        if self.args.tester.filter_out_cqt_DC_Nyq:
+            g_den = self.model.CQTransform.apply_hpf_DC(g_den)
+        g_xin = self.model.vjp(lincomb(torch.empty_like(g_den), cout, g_den))
+        g_x = lincomb(torch.empty_like(g_den), cskip, g_den, cin, g_xin)
+        normguide = g_x.double().pow(2).sum().sqrt() / self.args.exp.audio_len ** 0.5          # (whole batch, like torch.linalg.norm there)
+        return g_x * float(self.xi / (normguide + 1e-6) / float(t_i))
+
+    def compute_sweep(self, denoised_estimate, y):
+        """(:598-616) the fit objective ||w (|X| H(fc, A) - |Y|)|| and its gradient w.r.t. (fc, A) on the grid fc_s x A_s
+        (15 x 12, one break point): returns (norms [15,12], grads [15,12,2]) on the host.  One launch evaluates all 180 points
+        from the per-bin sufficient statistics (babe_filter_loss_grad); the reference runs 180 autograd passes."""
+        st = self.stft_ops(y.shape[-1], y.device)
+        if getattr(self, "fc_s", None) is None:
+            self.fc_s, self.A_s = torch.logspace(2.5, 4, 15), torch.linspace(-80, -5, 12)
+        stats = st.mag_stats(st.stft(denoised_estimate.contiguous()), st.stft(y.contiguous()), shared=True)
+        nf, na = self.fc_s.numel(), self.A_s.numel()
+        grid = torch.stack([self.fc_s.float().cpu().repeat_interleave(na), self.A_s.float().cpu().repeat(nf)], 1).unsqueeze(-1)
+        lg = st.filter_loss_grad(stats, grid.contiguous().to(y.device), self.fit_cfg).cpu()
+        return lg[:, 0].reshape(nf, na), lg[:, 1:3].reshape(nf, na, 2)
 
     # ---- clip-level pipelining -------------------------------------------------------------------------------------------
     # Clips are independent (per-clip semantics), so their whole evaluation chains - UNet forward, CQT, STFT, the
@@ -420,8 +517,7 @@ class BlindSampler:
 
     def predict_blind_bwe(self, y, rid=False, compute_sweep=False):
         """y [B,L] observations on the GPU -> (x, filter_params[, data_denoised, t, data_filters])  (:619-769)."""
-        if compute_sweep:
-            raise NotImplementedError("compute_sweep (logging only)")
+        # (compute_sweep is accepted and ignored, as in the reference: its blind loop :619-769 never reads the flag)
         B = y.shape[0]
         if self.batch_semantics == "per_clip" and B > self.max_in_flight and not rid:
             outs = [self._sample(y[i:i + self.max_in_flight], self._init_params(min(self.max_in_flight, B - i), y.device),
@@ -433,8 +529,6 @@ class BlindSampler:
         """Known-degradation variant (:306-364 -> predict_conditional :387-404 -> predict :406-498).
         filt_type 'fc_A' (filt = [2,K] breakpoints) or 'firwin' / 'firwin_hpf' (filt = FIR taps applied with
         conv1d(padding="same"), :211-218).  rid=True returns (x, data_denoised, data_score, t) like predict."""
-        if test_filter_fit or compute_sweep:
-            raise NotImplementedError("test_filter_fit / compute_sweep (logging only)")
         dev = ylpf.device
         if filt_type == "fc_A":
             p = torch.as_tensor(filt, dtype=torch.float32)
@@ -449,7 +543,8 @@ class BlindSampler:
             raise NotImplementedError(f"filt_type={filt_type!r}: 'fc_A' and 'firwin' run on the HIP path (the IIR / "
                                       f"resample degradations are torchaudio paths no target config uses)")
         try:
-            res = self._sample(ylpf, params, blind=False, rid=rid, snoise=self.diff_params.Snoise)
+            res = self._sample(ylpf, params, blind=False, rid=rid, snoise=self.diff_params.Snoise,
+                               diag=(bool(test_filter_fit), bool(compute_sweep)))
         finally:
             self.fir_taps = None
         return res if rid else res[0]

@@ -40,6 +40,7 @@ class Sampler(BlindSampler):
         self.fir_taps = None
         self.ar_mask = None
         self.dc = None
+        self.inpaint_mask = None
 
     def stft_ops(self, L, device):
         if self._stft is None or self._stft.L != L:
@@ -53,7 +54,9 @@ class Sampler(BlindSampler):
         # xi = 0: x0 = D(x) (no high-pass in this branch of the reference, :126), x0 <- y + x0 - A(x0), d = (x - x0) / t
         from ..stft import fir_same
         x_den = self.get_denoised_estimate(x, t, lane, hpf=False)
-        x0 = lincomb(torch.empty_like(x), 1.0, x_den, 1.0, y, -1.0, fir_same(x_den, self.fir_taps))
+        from ..stft import mask_blend
+        a0 = mask_blend(self.inpaint_mask, x_den, None) if self.inpaint_mask is not None else fir_same(x_den, self.fir_taps)
+        x0 = lincomb(torch.empty_like(x), 1.0, x_den, 1.0, y, -1.0, a0)
         return lincomb(torch.empty_like(x), 1.0 / float(t), x, -1.0 / float(t), x0), x_den, filter_params
 
     def predict_bwe(self, ylpf, filt, filt_type):
@@ -61,6 +64,16 @@ class Sampler(BlindSampler):
             raise NotImplementedError(f"filt_type={filt_type!r}: only FIR degradations run on the HIP path")
         self.fir_taps = torch.as_tensor(filt, dtype=torch.float32).reshape(-1).contiguous().to(ylpf.device)
         return self.predict_conditional(ylpf)
+
+    def predict_inpainting(self, y_masked, mask):
+        """Masking degradation A(x) = mask * x (edm_sampler.py:231-243 -> predict_conditional): y_masked [B,L], mask [L] or [B,L]
+        (1 = observed).  Guidance gradient through the mask, data-consistency replacement x0 <- y + x0 - mask * x0 if configured."""
+        self.fir_taps = None
+        self.inpaint_mask = torch.as_tensor(mask, dtype=torch.float32).contiguous().to(y_masked.device)
+        try:
+            return self.predict_conditional(y_masked)
+        finally:
+            self.inpaint_mask = None
 
     def predict_unconditional(self, shape, device):
         """Unguided sampling (edm_sampler.py:231-243 -> predict :166-229 with y = None)."""

@@ -41,7 +41,7 @@ def supported(smp, y, blind):
     """True when this evaluation is the default configuration babe_score_eval sequences."""
     m = smp.model
     return (y is not None and smp.norm == 2 and smp.stft_dist is None and smp.obs_snr is None and not smp.sigma_den
-            and smp.ar_mask is None and smp.fir_taps is None and smp.dc is None
+            and smp.ar_mask is None and smp.fir_taps is None and smp.dc is None and getattr(smp, "inpaint_mask", None) is None
             and not (smp._dc_cfg if blind else smp.data_consistency)
             and getattr(m, "precision", None) == "f32" and hasattr(m, "lane_engine"))
 

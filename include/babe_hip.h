@@ -360,6 +360,12 @@ typedef struct {
  * params [P][2][K] updated in place; n_iter[P] receives the iteration count. K <= 8. */
 int babe_filter_fit(const double* stats, float* params, int* n_iter, int P, int K, int nbins, float fs, int nfft,
                     const babe_fit_cfg* cfg, void* stream);
+/* The objective of that fit and its gradient at given parameters, no descent step (BlindSampler.optimizer_func + autograd,
+ * :523-533, as compute_sweep :598-616 evaluates them on a grid): lossgrad [P][1 + 2K] = loss, d loss / d fc_j, d loss / d A_j for
+ * each of the P parameter sets params [P][2][K]; stats_pstride: doubles between the statistics of consecutive sets (3 * nbins for
+ * one set each, 0 for ONE set of statistics shared by all P).  Reference-order kernel (cfg.kernel is ignored). */
+int babe_filter_loss_grad(const double* stats, long stats_pstride, const float* params, float* lossgrad, int P, int K,
+                          int nbins, float fs, int nfft, const babe_fit_cfg* cfg, void* stream);
 
 /* ---- known FIR degradation (config #1): F.conv1d(y[B,1,L], taps[1,1,ntaps], padding="same"),
  * testing/edm_sampler.py:245-252, utils/bandwidth_extension.py:76-95.  PyTorch pads (ntaps-1)/2 on the left and the

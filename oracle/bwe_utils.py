@@ -139,3 +139,23 @@ def fit_params(x_den, y, params, fs, nfft=4096, mu=(1000.0, 10.0), tol=(5e-3, 5e
             break
         prev = p.clone()
     return p, n_it
+
+
+def compute_sweep(x_den, y, fs, nfft=4096, weighting="sqrt", fc_s=None, A_s=None):
+    """BlindSampler.compute_sweep (testing/blind_bwe_sampler.py:598-616): the fit objective and its autograd gradient w.r.t.
+    (fc, A) for every point of the grid fc_s x A_s (one break point).  Returns (norms [nf, na], grads [nf, na, 2])."""
+    fc_s = torch.logspace(2.5, 4, 15) if fc_s is None else fc_s
+    A_s = torch.linspace(-80, -5, 12) if A_s is None else A_s
+    f = bin_freqs(nfft, fs)
+    Xm, Ym = stft(x_den, nfft).abs(), stft(y, nfft).abs()
+    w = freq_weight(Xm.shape[1], weighting)
+    norms = torch.zeros(len(fc_s), len(A_s))
+    grads = torch.zeros(len(fc_s), len(A_s), 2)
+    for i, fc in enumerate(fc_s):
+        for j, A in enumerate(A_s):
+            p = torch.tensor([float(fc), float(A)]).requires_grad_(True)
+            loss = mag_loss(Xm, Ym, design_filter(p[0:1], p[1:2], f), w)
+            g, = torch.autograd.grad(loss, p)
+            norms[i, j], grads[i, j] = loss.detach(), g
+    return norms, grads
+

@@ -148,7 +148,8 @@ class OracleEDMSampler:
         self.data_consistency = data_consistency          # posterior_sampling.data_consistency (edm_sampler.py:47-54, :113-130)
 
     def score(self, x, t, y, taps):
-        fir = lambda v: torch.nn.functional.conv1d(v.unsqueeze(1), taps.view(1, 1, -1), padding="same").squeeze(1)
+        # taps: FIR taps, or a callable degradation (predict_inpainting: v -> mask * v, edm_sampler.py:231-243)
+        fir = taps if callable(taps) else (lambda v: torch.nn.functional.conv1d(v.unsqueeze(1), taps.view(1, 1, -1), padding="same").squeeze(1))
         if self.xi <= 0:
             # :124-130 - no guidance: the denoised estimate with the replacement step, always
             with torch.no_grad():
@@ -168,7 +169,7 @@ class OracleEDMSampler:
         xd = E.denoiser(self.p, self.net, x, t.reshape(1, 1).expand(x.shape[0], 1))
         if self.hpf:
             xd = self.cqt.apply_hpf_DC(xd)
-        rec = torch.nn.functional.conv1d(xd.unsqueeze(1), taps.view(1, 1, -1), padding="same").squeeze(1)
+        rec = taps(xd) if callable(taps) else torch.nn.functional.conv1d(xd.unsqueeze(1), taps.view(1, 1, -1), padding="same").squeeze(1)
         norm = torch.linalg.norm(y - rec, dim=1, ord=2)
         g, = torch.autograd.grad(norm.sum(), x)
         s = self.xi / (torch.linalg.norm(g) / self.audio_len ** 0.5 * t + 1e-6)
@@ -194,6 +195,11 @@ class OracleEDMSampler:
             else:
                 x = x_hat + h * d
         return x.detach()
+
+
+def edm_predict_inpainting(smp, y_masked, mask, noises):
+    """OracleEDMSampler with the masking degradation of Sampler.predict_inpainting (edm_sampler.py:231-243)."""
+    return smp.predict_bwe(y_masked, lambda v: mask * v, noises)
 
 
 def smooth_mask(mask, size):

@@ -1025,6 +1025,66 @@ def g24(mu=None, probe=True):
          probe_moved_x=moved, probe_moved_fp=fmoved)
 
 
+# ---------------------------------------------------------------- G25: compute_sweep and the get_rec_grads helper
+def g25():
+    """testing/blind_bwe_sampler.py:598-616 compute_sweep (the fit objective and its autograd gradient on the 15 x 12 (fc, A)
+    grid of predict :439-440) on a synthetic (denoised estimate, observation) pair; and :75-135 get_rec_grads called as
+    get_score_rec_guidance :136-149 calls it (x requires grad -> get_denoised_estimate -> get_rec_grads), reduced-width network."""
+    args = small_args(T=3)
+    net, sd = build_ref_net(args)
+    L, fs = args.exp.audio_len, args.exp.sample_rate
+    with quiet():
+        s = samp_mod.BlindSampler(net, edm_mod.EDM(args), args)
+    g = torch.Generator().manual_seed(2525)
+    y = synth_obs(L, fs, g, fc=3000.0, A=-25.0)
+    den = y + 0.02 * torch.randn(1, L, generator=g)
+    s.fc_s, s.A_s = torch.logspace(2.5, 4, 15), torch.linspace(-80, -5, 12)
+    s.freqs = torch.fft.rfftfreq(args.tester.blind_bwe.NFFT, d=1 / fs)        # (set by predict_bwe / predict_blind_bwe, :275, :629)
+    with quiet():
+        norms, grads = s.compute_sweep(den, y)
+    # the guidance helper at one noise level, fc_A degradation with a 2-break-point filter
+    fp = torch.tensor([[2500.0, 6000.0], [-20.0, -45.0]])
+    x = (y + 0.05 * torch.randn(1, L, generator=g)).requires_grad_(True)
+    t = torch.tensor(0.05)
+    x_hat = s.get_denoised_estimate(x, t)
+    rg = s.get_rec_grads(x_hat, y.clone(), x, t, lambda xx, p: s.apply_filter_fcA(xx, p), fp)
+    save("sweep_helpers.npz", seed=2525, y=y, den=den, norms=norms, grads=grads, fp=fp, x=x.detach(), t=t, x_hat=x_hat.detach(), rec_grads=rg.detach())
+
+
+# ---------------------------------------------------------------- G26: edm_sampler.Sampler.predict_inpainting
+def g26():
+    """testing/edm_sampler.py:231-243 predict_inpainting (degradation = mask * x) -> predict_conditional -> predict :166-229, T = 3,
+    recorded noise, tester config edm_DC_correction_4s.yaml as g9; a 0/1 mask with two gaps."""
+    esm = importlib.import_module("testing.edm_sampler")
+    args = small_args(T=3)
+    import yaml
+    with open(f"{ref_shim.REF}/conf/tester/edm_DC_correction_4s.yaml") as f:
+        args.tester = ref_shim.to_attr(yaml.safe_load(f))
+    args.tester.T = 3
+    net, sd = build_ref_net(args)
+    with quiet():
+        s = esm.Sampler(ResidualNetRef(net, 0.3, 0.063), edm_mod.EDM(args), args)
+    L = args.exp.audio_len
+    g = torch.Generator().manual_seed(2626)
+    clean = 0.1 * torch.randn(1, L, generator=g)
+    mask = torch.ones(1, L)
+    mask[:, 20000:26000] = 0
+    mask[:, 60000:61500] = 0
+    y = mask * clean
+    noises = [torch.randn(1, L, generator=g) for _ in range(1 + args.tester.T)]
+    it = iter(noises)
+    orig = torch.randn
+    torch.randn = lambda *a, **k: next(it)
+    try:
+        with quiet(), contextlib.redirect_stderr(io.StringIO()):
+            xr = s.predict_inpainting(y.clone(), mask)
+    finally:
+        torch.randn = orig
+    save("edm_sampler_inpainting.npz", seed=2626, res_a=0.3, y=y, mask=mask, x=xr, xi=args.tester.posterior_sampling.xi,
+         ro=args.tester.diff_params.ro, sigma_max=args.tester.diff_params.sigma_max, Schurn=args.tester.diff_params.Schurn,
+         data_consistency=int(bool(args.tester.posterior_sampling.data_consistency)))
+
+
 # ---------------------------------------------------------------- G21: formal_test_bwe, non-AR segmentation + Hann OLA
 def g21():
     """testing/blind_bwe_tester.py:320-578 BlindTester.formal_test_bwe(typefilter='fc_A', blind=True) with
@@ -1170,6 +1230,6 @@ def g23():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24"]
+    which = sys.argv[1:] or ["g1", "g2_5", "g6", "g7_8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26"]
     for w in which:
         globals()[w]()

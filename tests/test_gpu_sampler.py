@@ -657,3 +657,97 @@ def test_blind_sampler_nfft_1024():
     for i in range(3):
         assert params_close(dfil[i], s["data_filters"][i]), (i, dfil[i], s["data_filters"][i])
     assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 2e-3 and params_close(fp, s["filter_params"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6: the reference's diagnostics and helper methods (tests/golden/make_golden.py::g25)
+
+def test_compute_sweep_vs_reference_golden():
+    """BlindSampler.compute_sweep (testing/blind_bwe_sampler.py:598-616): fit objective and gradient on the 15 x 12 (fc, A) grid,
+    ONE launch from the per-bin statistics (babe_filter_loss_grad) against the reference's 180 autograd passes."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    s = load("sweep_helpers.npz")
+    g, args, net = small_net(T=3)
+    smp = BlindSampler(net, EDM(args), args)
+    norms, grads = smp.compute_sweep(s["den"].cuda(), s["y"].cuda())
+    assert norms.shape == (15, 12) and grads.shape == (15, 12, 2)
+    en = float((norms - s["norms"]).abs().max() / s["norms"].abs().max())
+    eg = float((grads - s["grads"]).abs().max() / s["grads"].abs().max())
+    print(f"compute_sweep: norms {en:.2e}, grads {eg:.2e} (relative to the largest entry)")
+    assert en < 1e-5 and eg < 1e-4
+
+
+def test_reference_helper_methods_vs_golden():
+    """get_denoised_estimate + get_rec_grads under the reference's signature (:75-135, called as get_score_rec_guidance :136-149
+    does), apply_filter_fcA (:518-520), fit_params on signals (:533-595) and move_timestep (:509-516)."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    s = load("sweep_helpers.npz")
+    g, args, net = small_net(T=3)
+    smp = BlindSampler(net, EDM(args), args)
+    x, y, t = s["x"].cuda(), s["y"].cuda(), float(s["t"])
+    x_hat = smp.get_denoised_estimate(x, t)
+    assert rel(x_hat, s["x_hat"]) < 1e-4
+    rg = smp.get_rec_grads(x_hat, y, x, t, None, s["fp"])
+    print(f"get_rec_grads: rel {rel(rg, s['rec_grads']):.2e}")
+    assert rel(rg, s["rec_grads"]) < 1e-3
+    # apply_filter_fcA = design_filter + apply_filter (pinned by stft_filter.npz): here against the composite of the ops
+    st = smp.stft_ops(y.shape[1], y.device)
+    assert torch.equal(smp.apply_filter_fcA(y, s["fp"]), st.apply_filter(y, st.design_filter(s["fp"].cuda())))
+    # fit_params on signals == the spectra form the loop uses
+    p0 = smp._init_params(1, y.device)
+    a = smp.fit_params_signal(s["den"].cuda(), y, p0[0])
+    b, _ = smp.fit_params(st.stft(s["den"].cuda()), st.stft(y), p0)
+    assert torch.equal(a, b[0])
+    # move_timestep: x_hat = x + sqrt(t_hat^2 - t^2) Snoise eps with the sampler's own noise source
+    eps = torch.randn(1, y.shape[1], generator=torch.Generator().manual_seed(1))
+    smp._randn = lambda shape, device: eps.to(device)
+    xh, th = smp.move_timestep(x, torch.tensor(0.05), torch.tensor(0.2), 1.0)
+    assert abs(float(th) - 0.06) < 1e-7 and rel(xh, x.cpu() + (0.06 ** 2 - 0.05 ** 2) ** 0.5 * eps) < 1e-6
+
+
+def test_known_filter_run_with_the_diagnostics():
+    """predict_bwe(..., 'fc_A', rid=True, test_filter_fit=True, compute_sweep=True) (predict :419-466): the diagnostics run on the
+    guided Tweedie estimate of every step and leave the trajectory untouched."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.blind_bwe_sampler import BlindSampler
+    s = load("sweep_helpers.npz")
+    g, args, net = small_net(T=3)
+    smp = BlindSampler(net, EDM(args), args)
+    y, L = s["y"].cuda(), s["y"].shape[1]
+    noises = [torch.randn(1, L, generator=torch.Generator().manual_seed(40 + i)) for i in range(4)]
+    outs = []
+    for flags in (dict(), dict(test_filter_fit=True, compute_sweep=True)):
+        it = iter(noises)
+        smp._randn = lambda shape, device: next(it).to(device)
+        outs.append(smp.predict_bwe(y, s["fp"], "fc_A", rid=True, **flags))
+    assert len(outs[0]) == 4 and len(outs[1]) == 7
+    assert torch.equal(outs[0][0], outs[1][0])                                 # same trajectory
+    fits, norms, grads = outs[1][4:]
+    assert fits.shape == (3, 2, 5) and norms.shape == (3, 15, 12) and grads.shape == (3, 15, 12, 2)
+    assert torch.isfinite(fits).all() and torch.isfinite(norms).all() and (norms > 0).all()
+
+
+def test_edm_sampler_inpainting_T3_vs_reference_golden():
+    """edm_sampler.Sampler.predict_inpainting (testing/edm_sampler.py:231-243): guidance through A(x) = mask * x."""
+    from babe_amd.diff_params.edm import EDM
+    from babe_amd.testing.edm_sampler import Sampler
+    s = load("edm_sampler_inpainting.npz")
+    g, args, net = small_net(T=3)
+    args.tester.posterior_sampling.xi = float(s["xi"])
+    args.tester.posterior_sampling.data_consistency = bool(int(s["data_consistency"]))
+    args.tester.diff_params.ro = float(s["ro"])
+    args.tester.diff_params.sigma_max = float(s["sigma_max"])
+    args.tester.diff_params.Schurn = float(s["Schurn"])
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    smp = Sampler(ResidualNet(net, float(s["res_a"]), 0.063), EDM(args), args)
+    it = iter(noises)
+    smp._randn = lambda shape, device: next(it).to(device)
+    x = smp.predict_inpainting(s["y"].cuda(), s["mask"])
+    print(f"inpainting: RMS err {rms_err(x, s['x']):.2e}, rel {rel(x, s['x']):.2e}")
+    assert rms_err(x, s["x"]) < 1e-3 and rel(x, s["x"]) < 2e-3
+    assert smp.inpaint_mask is None

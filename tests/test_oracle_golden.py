@@ -118,3 +118,12 @@ def test_small_ops():
         assert rel(UN.resample_up(g[f"rs.x{T}"]), g[f"rs.up{T}"]) < 1e-6
     sd = {"embedding." + k[len("rff.sd."):]: v for k, v in g.items() if k.startswith("rff.sd.")}
     assert rel(UN.embedding(sd, g["rff.s"]), g["rff.y"]) < 1e-6
+
+
+def test_compute_sweep_vs_reference_golden():
+    """oracle compute_sweep (fit objective + autograd gradient on the 15 x 12 (fc, A) grid) vs the reference's own
+    BlindSampler.compute_sweep (testing/blind_bwe_sampler.py:598-616; tests/golden/make_golden.py::g25)."""
+    s = load("sweep_helpers.npz")
+    norms, grads = U.compute_sweep(s["den"], s["y"], 22050)
+    assert float((norms - s["norms"]).abs().max() / s["norms"].abs().max()) < 1e-5
+    assert float((grads - s["grads"]).abs().max() / s["grads"].abs().max()) < 1e-4

@@ -373,3 +373,20 @@ def test_sampler_full_width_vs_reference_golden():
     rms = float((x - s["x0"]).pow(2).mean().sqrt())
     assert rms < 1e-3 and rel(x, s["x0"]) < 1e-3, (rms, rel(x, s["x0"]))
     assert params_close(fp, s["fp0"])
+
+
+def test_edm_sampler_inpainting_T3():
+    """edm_sampler.Sampler.predict_inpainting (masking degradation, /root/reference/testing/edm_sampler.py:231-243; G26)."""
+    from oracle.sampler import OracleEDMSampler, edm_predict_inpainting
+    g, sd, cqt = small_net()
+    s = load("edm_sampler_inpainting.npz")
+    L = 92092
+    gen = torch.Generator().manual_seed(int(s["seed"]))
+    _ = torch.randn(1, L, generator=gen)
+    noises = [torch.randn(1, L, generator=gen) for _ in range(4)]
+    a = float(s["res_a"])
+    p = E.EDMParams(0.063, 1e-4, float(s["sigma_max"]), float(s["ro"]), Schurn=float(s["Schurn"]), Stmin=0, Stmax=50, Snoise=1.0)
+    net = lambda x, cn: a * UN.unet_forward(sd, CFG, cqt, x, cn) + (torch.exp(4 * cn) / 0.063) * x
+    smp = OracleEDMSampler(net, cqt, p, audio_len=L, T=3, xi=float(s["xi"]), data_consistency=bool(int(s["data_consistency"])))
+    x = edm_predict_inpainting(smp, s["y"], s["mask"], noises)
+    assert rel(x, s["x"]) < 1e-3
