@@ -370,9 +370,10 @@ class CQT_nsgt:
 
     def __del__(self):
         try:
-            if getattr(self, "_plan", None):
-                lib().babe_cqt_plan_destroy(self._plan)
-                self._plan = None
+            for k in ("_plan", "_plan_eval"):                                 # (_plan_eval: created by testing/eval_c.py)
+                if getattr(self, k, None):
+                    lib().babe_cqt_plan_destroy(getattr(self, k))
+                    setattr(self, k, None)
         except Exception:                                                     # interpreter shutdown  noqa: BLE001
             pass
 

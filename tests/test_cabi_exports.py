@@ -171,3 +171,28 @@ def test_f45_dispatch_rule_is_host_logic():
     # the benchmark's part-filled geometries: 320 rows at dilation 32 (0.83: taken), 384 rows at dilation 64 (0.75: left to F(2,5) x F(4,3))
     assert pre(F=320, T=256, dil=32) == 1 and pre(F=384, T=128, dil=64, Cin=256, Cout=256) == 0
     assert pre(F=448, T=64, dil=64, Cin=256, Cout=256) == 1 and pre(F=320, T=256, dil=16) == 1
+
+
+def test_plan_entry_points_refuse_bad_arguments_without_a_gpu():
+    """Host-side validation of the round-6 plan entry points (no GPU call is made on these paths): NULL handles, NULL buffers and
+    an empty descriptor are refused with a message instead of being dereferenced."""
+    from babe_amd._lib import lib
+    from babe_amd.testing import eval_c
+    eval_c._register()
+    L = lib()
+    L.babe_last_error.restype = ctypes.c_char_p
+    L.babe_cqt_workspace_bytes.restype = ctypes.c_long
+    L.babe_cqt_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert L.babe_cqt_workspace_bytes(None, 4) == -1
+    for name in ("babe_cqt_fwd", "babe_cqt_bwd", "babe_cqt_fwd_adjoint", "babe_cqt_bwd_adjoint", "babe_cqt_hpf"):
+        fn = getattr(L, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p]
+        assert fn(None, None, None, None, 1, None) < 0 and b"bad arguments" in L.babe_last_error()
+    d = eval_c.EvalDesc()
+    assert L.babe_eval_workspace_bytes(ctypes.byref(d), 1) == -1 and b"bad descriptor" in L.babe_last_error()
+    assert L.babe_score_eval(ctypes.byref(d), None, 0.1, 1.0, 1.0, 1.0, 0.0, None, None, None, None, None, None, None, 0, 1, None) < 0
+    L.babe_filter_loss_grad.restype = ctypes.c_int
+    L.babe_filter_loss_grad.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert L.babe_filter_loss_grad(None, 0, None, None, 1, 1, 2049, 44100.0, 4096, None, None) < 0

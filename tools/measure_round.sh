@@ -1,14 +1,16 @@
 #!/bin/bash
 # Round measurement suite (run on the GPU box through gpurun): writes everything under gpurun_out/$1/ with prefix $2 (e.g. r05)
-# usage: tools/measure_round.sh r5m r05
+# usage: tools/measure_round.sh r6m r06
 set -x
 out=gpurun_out/$1
-pre=${2:-r05}
+pre=${2:-r06}
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 python3 -m pytest tests -m gpu -q -s > $out/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $out/gpu_tests.log
 # the library-side UNet sequencer must not rot: the network / sampler parity files once more with BABE_UNET_C=1
 BABE_UNET_C=1 python3 -m pytest tests/test_gpu_unet_c.py tests/test_gpu_unet_full.py tests/test_gpu_sampler.py -m gpu -q > $out/gpu_tests_unet_c.log 2>&1; echo "pytest rc=$?" >> $out/gpu_tests_unet_c.log
+# ... and the library-side CQT plan + whole score evaluation (round 6): the sampler parity files with every evaluation as ONE C call
+BABE_EVAL_C=1 BABE_CQT_C=1 python3 -m pytest tests/test_gpu_sampler.py tests/test_gpu_cqt.py tests/test_gpu_eval_c.py -m gpu -q > $out/gpu_tests_eval_c.log 2>&1; echo "pytest rc=$?" >> $out/gpu_tests_eval_c.log
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2> $out/bench.err
 python3 tools/overlap_timeline.py > $out/overlap.txt 2> $out/overlap.err
 python3 tools/conv_shapes_bench.py > $out/conv_shapes_fwd.txt 2>&1
@@ -23,6 +25,9 @@ SHAPES=enc3.H0,enc5.H0,enc6.H0 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_I
 python3 tools/pmc_summary.py $out/pmc_insts conv_wino85 >> $out/pmc_wino85.txt
 python3 tools/f45_check.py > $out/f45_check.txt 2>&1
 python3 tools/cqt_bench.py > $out/cqt_bench.txt 2>&1
+BS=1,2,8,32 rocprofv3 --kernel-trace --output-format csv -d $out/cqt_trace -- python3 tools/cqt_bench.py > /dev/null 2>&1
+python3 tools/cqt_trace_summary.py $out/cqt_trace > $out/cqt_trace_summary.txt; rm -rf $out/cqt_trace
+python3 tools/fit_kernel_ab.py > $out/fit_kernel_ab.txt 2>&1
 python3 tools/filter_fit_bench.py > $out/filter_fit.txt 2>&1
 python3 tools/host_enqueue_time.py > $out/host_enqueue_time.txt 2>&1
 python3 tools/denoiser_bench.py > $out/denoiser_bench.txt 2>&1
