@@ -483,12 +483,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
 // and 3 one multiplying wave plus a transform wave carrying four wave-shares of transform: about the same time.  NW = 4: every SIMD
 // hosts one of each.  The multiplying waves' memory queue holds weights only, the transform waves' rows only (two register sets: the
 // rows of super-slab S + 2 are in flight while S + 1 is transformed).  One barrier per super-slab, as in the 128-channel kernel.
-template <bool HAS_ISC, int NW>
-__global__ __launch_bounds__(512, 1) void conv_wino85s_kernel(babe_conv_args a, Wino85Geom g, const float* __restrict__ wq) {
+// NWV = 12 (round 6, BABE_W85_12W=1): the 128-channel tile as 8 multiplying + 4 transform waves, three waves per SIMD at <= 168
+// registers - the multiplying waves never carry the transform in their own instruction stream.
+template <bool HAS_ISC, int NW, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_args a, Wino85Geom g, const float* __restrict__ wq) {
 #if __HIP_DEVICE_COMPILE__
     constexpr int KS = 16, KQ = 4, NU = 16, BN = 16 * NW, RD = W85_RD;
-    constexpr int TW = 8 - NW, PPL = 4 / TW;            // transform waves; channel quads per transform wave
-    static_assert(NW == 6 || NW == 4, "tile width");
+    constexpr int TW = NWV - NW, PPL = 4 / TW;          // transform waves; channel quads per transform wave
+    static_assert((NWV == 8 && (NW == 6 || NW == 4)) || (NWV == 12 && NW == 8), "tile width");
     constexpr int XSZ = KS * NU * 6;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     f32x4* const Xb = reinterpret_cast<f32x4*>(smem_f);  // X[2]
@@ -832,7 +834,11 @@ extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino8
     if (g.xcd) grid = dim3(8 * g.per_xcd, 1, a.B);
     const hipStream_t st = (hipStream_t)stream;
     const bool isc = a.in_scale != nullptr;
-    if (bn == 128) {
+    static const int w12 = [] { const char* e = getenv("BABE_W85_12W"); return e ? atoi(e) : 0; }();
+    if (bn == 128 && w12) {
+        if (isc) hipLaunchKernelGGL((conv_wino85s_kernel<true, 8, 12>), grid, dim3(768), lds, st, a, g, w_wino85);
+        else hipLaunchKernelGGL((conv_wino85s_kernel<false, 8, 12>), grid, dim3(768), lds, st, a, g, w_wino85);
+    } else if (bn == 128) {
         if (isc) hipLaunchKernelGGL((conv_wino85_kernel<true>), grid, dim3(512), lds, st, a, g, w_wino85);
         else hipLaunchKernelGGL((conv_wino85_kernel<false>), grid, dim3(512), lds, st, a, g, w_wino85);
     } else if (bn == 96) {
