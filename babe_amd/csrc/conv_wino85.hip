@@ -26,11 +26,14 @@
 // 96- and 64-channel tiles: conv_wino85s_kernel below - waves 0 .. NW-1 only multiply, waves NW .. 7 only load and transform, which
 // balances the four SIMDs where six (four) multiplying waves alone cannot.  All three produce the same sums in the same order for a
 // given (co, output): a conv run as 64-channel tiles equals the same conv run as one 128-channel tile bit for bit.
+// Round 6: the 128-channel tile runs by default as conv_wino85s_kernel<., 8, 12> - 8 multiplying + 4 transform waves, three per SIMD
+// at 159 registers (babe_conv2d_wino85_set_waves / BABE_W85_12W=0 for the 8-wave form below): +3 % on the whole job.
 // Measured (profiles/r05_f45_check.txt, MI355X, us per launch F45 / F(2,5)xF(4,3)): 128 ch 164 / 205, 256 ch 273 / 350, 96 ch
 // 212 / 268, 64 ch 109 / 145; whole job 2.136 -> 2.40 audio-sec/s.
 #include "common.h"
 #include "../../include/babe_hip.h"
 #include "prof.h"
+#include <atomic>
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -626,6 +629,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
     }
 
     // ================= multiplying waves =================
+    // (a static s_setprio 1 / 3 for these waves over the transform wave of their SIMD: no effect, profiles/r06_12wave_ab.txt)
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, 4 * g.CinP * g.CoutP * 48, 0x00020000);
     const int NT = g.CoutP >> 4;
     const int wstep = NT * 3072;
@@ -812,6 +816,19 @@ extern "C" int babe_conv2d_wino85_preferred(const babe_conv_args* ap) {
     return wino85_fill(*ap) >= min_fill ? 1 : 0;
 }
 
+/* Form of the 128-channel tile: 12 = 8 multiplying + 4 transform waves (conv_wino85s_kernel<., 8, 12>, round 6, the default:
+ * +3 % on the whole job, profiles/r06_12wave_ab.txt), 8 = conv_wino85_kernel (waves 0-3 transform and multiply).  Same sums in
+ * the same order: bit-identical outputs.  BABE_W85_12W=0 selects 8 for the process; babe_conv2d_wino85_set_waves at run time. */
+static std::atomic<int>& w85_waves128() {
+    static std::atomic<int> v{[] { const char* e = getenv("BABE_W85_12W"); return (e && atoi(e) == 0) ? 8 : 12; }()};
+    return v;
+}
+extern "C" int babe_conv2d_wino85_set_waves(int waves) {
+    BABE_CHECK_ARG(waves == 8 || waves == 12, "conv2d_wino85_set_waves: 8 or 12 (got %d)", waves);
+    w85_waves128().store(waves, std::memory_order_relaxed);
+    return BABE_OK;
+}
+
 extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino85, void* stream) {
     BABE_CHECK_ARG(ap && w_wino85, "conv2d_wino85: null args");
     BABE_CHECK_ARG(babe_conv2d_wino85_supported(ap), "conv2d_wino85: unsupported problem");
@@ -834,8 +851,7 @@ extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino8
     if (g.xcd) grid = dim3(8 * g.per_xcd, 1, a.B);
     const hipStream_t st = (hipStream_t)stream;
     const bool isc = a.in_scale != nullptr;
-    static const int w12 = [] { const char* e = getenv("BABE_W85_12W"); return e ? atoi(e) : 0; }();
-    if (bn == 128 && w12) {
+    if (bn == 128 && w85_waves128().load(std::memory_order_relaxed) == 12) {
         if (isc) hipLaunchKernelGGL((conv_wino85s_kernel<true, 8, 12>), grid, dim3(768), lds, st, a, g, w_wino85);
         else hipLaunchKernelGGL((conv_wino85s_kernel<false, 8, 12>), grid, dim3(768), lds, st, a, g, w_wino85);
     } else if (bn == 128) {

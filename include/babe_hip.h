@@ -180,6 +180,9 @@ int babe_conv_pack_weights_wino85(const float* w, float* dst, int Cout, int Cin,
 int babe_conv2d_wino85_supported(const babe_conv_args* a);
 int babe_conv2d_wino85_preferred(const babe_conv_args* a);
 int babe_conv2d_wino85(const babe_conv_args* a, const float* w_wino85, void* stream);
+/* Form of the kernel's 128-channel tile: 12 (default; 8 multiplying + 4 transform waves, three per SIMD) or 8 (round 5: waves 0-3
+ * transform and multiply).  Bit-identical outputs; BABE_W85_12W=0 selects 8 for the process. */
+int babe_conv2d_wino85_set_waves(int waves);
 
 /* ---- the whole UNet body from one call: networks/cqtdiff+.py:746-839 (forward), ResnetBlock :452-493, and its input-VJP
  * (the autograd pass of testing/blind_bwe_sampler.py:120).  csrc/unet_engine.hip sequences the op-level functions of this header

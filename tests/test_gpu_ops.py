@@ -775,8 +775,10 @@ def test_f45_tile_widths_are_bit_identical(ops):
     specialised waves) do the same arithmetic in the same order for a given output: a 128-channel conv on the first equals, bit for
     bit, the same conv done as two 64-channel convs on the second; a 192-channel conv (two 96-channel tiles) equals three
     64-channel convs."""
-    from babe_amd._lib import dispatch_counts
-    for Cout, Cin, Fq, T, dil in ((128, 128, 48, 128, 2), (192, 96, 32, 196, 1)):
+    from babe_amd._lib import dispatch_counts, lib
+    for Cout, Cin, Fq, T, dil, waves in ((128, 128, 48, 128, 2, 12), (128, 128, 48, 128, 2, 8), (192, 96, 32, 196, 1, 12), (256, 128, 56, 64, 8, 12)):
+        # (round 6: the 128-channel tile as 8 multiplying + 4 transform waves - the default - and as the 8-wave kernel)
+        assert lib().babe_conv2d_wino85_set_waves(waves) == 0
         g = torch.Generator().manual_seed(Cout + Cin)
         x = torch.randn(2, Cin, Fq, T, generator=g).cuda()
         w = (torch.randn(Cout, Cin, 5, 3, generator=g) / math.sqrt(Cin * 15)).cuda()
@@ -789,6 +791,7 @@ def test_f45_tile_widths_are_bit_identical(ops):
             ops.conv2d(x, ops.PackedConv(w[c0:c0 + 64].contiguous()), parts[:, c0:c0 + 64], dil=dil, in_scale=isc, force_f45=True)
         assert dispatch_counts()["conv53_wino85"] == 1 + Cout // 64
         assert torch.equal(out, parts), float((out - parts).abs().max())
+    assert lib().babe_conv2d_wino85_set_waves(12) == 0
 
 
 def test_conv2d_f45_dispatch_rule_and_tile_order(ops):
