@@ -554,6 +554,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
             }
         // the rows of super-slab (ps, ci0) into register set `st` (rows 0 and 7 in pass B only), its halo and input scale
         auto issue = [&](int st, int ps, int ci0) __attribute__((always_inline)) {
+            if (W85_ABL & 2) return;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 const int so = (ci0 + 4 * (vw0 + p)) * cs1 * 4;
@@ -578,6 +579,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
                     asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(xh[r]) : "v"(hsrc), "v"(xhl[st][p]), "n"(32 * r));
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]), "+v"(xh[5]), "+v"(xh[6]), "+v"(xh[7]));
                 const int xl = (((vw0 + p) * 4 + s_ch) * NU + s_tu) * 6;
+                if (W85_ABL & 1) {
+                    buf[xl] = xv[st][p][1] + xv[st][p][0];
+                    buf[xl + 3] = xv[st][p][2] + xv[st][p][7] + f32x4{xh[1], xh[2], xh[0], xh[7]};
+                    continue;
+                }
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     f32x4 o0, o1, o2;
@@ -637,6 +643,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
     int sW = ((co0 >> 4) + wave) * 3072;
     const unsigned wvo = (unsigned)(lane * 16);
     auto w_next = [&]() __attribute__((always_inline)) {
+        if (W85_ABL & 256) return;                      // (timing ablation: always the first half-slot - L1 hits)
         sW += wstep;
         sW = sW < sWend ? sW : sWend;
     };
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
     f32x4 aw[RD];
 #pragma unroll
     for (int i = 0; i < RD; ++i) {
-        aw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo, sW + (i % 3) * 1024, 0));
+        aw[i] = (W85_ABL & 4) ? f32x4{1.f, 2.f, 3.f, 4.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo, sW + (i % 3) * 1024, 0));
         if (i % 3 == 2) w_next();
     }
     f32x4 acc[2][12];
@@ -653,15 +660,21 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
 #pragma unroll
         for (int p = 0; p < 12; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bv[2];
+    bv[0] = bv[1] = f32x4{1.f, 2.f, 3.f, 4.f};
     __builtin_amdgcn_s_barrier();                          // X[0] is complete
     Y_FENCE
+#if W85_ABL & 8
+#define Z_READ(c, Xp, hs, pg) asm volatile("" : "+v"(bv[c]));
+#else
 #define Z_READ(c, Xp, hs, pg) bv[c] = (Xp)[boff + ((hs) >> 1) * KQ * NU * 6 + ((hs) & 1) * 3 + (pg)];
+#endif
 #define Z_MFMA(c, GN)                                                  \
+    if (!(W85_ABL & 16))                                               \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
         acc[((GN) / 3) & 1][4 * ((GN) % 3) + i] =                      \
             __builtin_amdgcn_mfma_f32_16x16x4f32(aw[(GN) % RD][i], bv[c][i], acc[((GN) / 3) & 1][4 * ((GN) % 3) + i], 0, 0, 0);
 #define Z_WLOAD(GN)                                                                                                          \
-    aw[(GN) % RD] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo, sW + ((GN) % 3) * 1024, 0)); \
+    if (!(W85_ABL & 4)) aw[(GN) % RD] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo, sW + ((GN) % 3) * 1024, 0)); \
     if constexpr ((GN) % 3 == 2) w_next();
 #define Z_G(GN)                                                        \
     Z_READ(((GN) + 1) & 1, Xs, ((GN) + 1) / 3, ((GN) + 1) % 3)         \

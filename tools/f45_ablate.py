@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         res.append(e0.elapsed_time(e1) / 20 * 1e3)
     print(" ".join(f"{r:8.1f}" for r in res))
     sys.exit(0)
-names = {0: "full kernel", 1: "no transform arithmetic", 2: "no row loads", 4: "no weight DMA", 8: "no operand reads", 16: "no MFMA",
+names = {0: "full kernel", 256: "weights always from the first half-slot (L1 hits)", 1: "no transform arithmetic", 2: "no row loads", 4: "no weight DMA", 8: "no operand reads", 16: "no MFMA",
          3: "no loads, no transform", 7: "no loads / transform / DMA", 15: "MFMA only", 512: "no epilogue", 1024: "no pass carry",
          527: "MFMA only, no epilogue", 1551: "MFMA only, no epilogue, no carry", 2048: "epilogue without stores",
          4096: "epilogue stores raw accumulators"}
