@@ -359,13 +359,15 @@ class CQT_nsgt:
         cw[0] = cw[-1] = 1.0 / L
         self.hpf_irfft = tf(d["hpf"] * cw)                # hpf * c_k / L   (irfft weights folded in)
         self.irfft_w = tf(cw)
-        # BABE_CQT_C=1: every transform below is ONE call into the library's own plan (csrc/cqt_plan.hip: band design in C++, device
-        # tables, sequencing) - the path a non-Python host takes; default: this class sequences the kernels from the numpy design
+        # Every transform below is ONE call into the library's own plan (csrc/cqt_plan.hip: band design in C++, device tables,
+        # sequencing) - the path a non-Python host takes, and since round 6 the default, so that this class, babe_score_eval and a
+        # C host all run on the SAME tables.  BABE_CQT_C=0: this class sequences the kernels from the numpy design (kept as the
+        # cross-check of the library's design: tests/test_cqt_plan_cpu.py, tests/test_gpu_cqt.py).
         self._plan = None
-        if os.environ.get("BABE_CQT_C", "0") == "1":
-            self._plan = lib().babe_cqt_plan_create(float(fs), self.Ls, numocts, binsoct, float(window[1]))
-            if not self._plan:
-                check(-1, "cqt_plan_create")
+        if os.environ.get("BABE_CQT_C", "1") == "1":
+            # (NULL for a length whose factors the mixed-radix FFT does not cover: this class then sequences the kernels itself,
+            # with the dense-DFT form of the length-L transform)
+            self._plan = lib().babe_cqt_plan_create(float(fs), self.Ls, numocts, binsoct, float(window[1])) or None
             self._ws = {}
 
     def __del__(self):

@@ -37,13 +37,24 @@ def _register():
     _registered = True
 
 
+def cqt_plan_of(cq):
+    """The library-side plan of a CQT_nsgt object: its own (the default), or one made here for an object that sequences the kernels
+    itself (BABE_CQT_C=0); None where the library cannot plan the length."""
+    _register()
+    if getattr(cq, "_plan", None):
+        return cq._plan
+    if getattr(cq, "_plan_eval", None) is None:
+        cq._plan_eval = lib().babe_cqt_plan_create(float(cq.fs), cq.Ls, cq.numocts, cq.binsoct, float(cq.design["beta"])) or 0
+    return cq._plan_eval or None
+
+
 def supported(smp, y, blind):
     """True when this evaluation is the default configuration babe_score_eval sequences."""
     m = smp.model
     return (y is not None and smp.norm == 2 and smp.stft_dist is None and smp.obs_snr is None and not smp.sigma_den
             and smp.ar_mask is None and smp.fir_taps is None and smp.dc is None and getattr(smp, "inpaint_mask", None) is None
             and not (smp._dc_cfg if blind else smp.data_consistency)
-            and getattr(m, "precision", None) == "f32" and hasattr(m, "lane_engine"))
+            and getattr(m, "precision", None) == "f32" and hasattr(m, "lane_engine") and cqt_plan_of(m.CQTransform) is not None)
 
 
 class CEval:
@@ -59,11 +70,7 @@ class CEval:
             root._eval_cunet = CUnet(root)
         self.cu = root._eval_cunet if eng is root else root._eval_cunet.clone(eng)
         cq = net.CQTransform
-        if not getattr(cq, "_plan", None) and not getattr(cq, "_plan_eval", None):
-            cq._plan_eval = lib().babe_cqt_plan_create(float(cq.fs), cq.Ls, cq.numocts, cq.binsoct, float(cq.design["beta"]))
-            if not cq._plan_eval:
-                check(-1, "cqt_plan_create")
-        self.cq_plan = getattr(cq, "_plan", None) or cq._plan_eval
+        self.cq_plan = cqt_plan_of(cq)
         d = EvalDesc()
         d.unet_plan, d.unet_state, d.cqt_plan, d.L = self.cu.plan, self.cu.state, self.cq_plan, cq.Ls
         d.rff_freq, d.rff_n = ptr(eng.rff_freq), eng.rff_freq.numel()

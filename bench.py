@@ -265,6 +265,10 @@ def main():
                          "fp32 storage+accumulation (reported with their own dtype string, never as f32)")
     ap.add_argument("--dry-run", action="store_true",
                     help="print the rank -> device -> clip-range table of this command (JSON) and exit: no GPU, no process group")
+    ap.add_argument("--no-eval-c", action="store_true",
+                    help="the Python kernel sequencer (~1200 C-ABI calls per evaluation) instead of ONE library call per score "
+                         "evaluation (babe_score_eval on the UNet / CQT plans, the default; bit-identical results): what the "
+                         "sequencing itself costs")
     ap.add_argument("--no-pin", action="store_true", help="do not pin this rank's host threads to its own block of CPUs")
     ap.add_argument("--profile-steps", type=int, default=1,
                     help="timed steps whose launches are bracketed by HIP events (0 = no roofline/hbm blocks)")
@@ -319,6 +323,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if a.no_eval_c:
+        os.environ["BABE_EVAL_C"] = "0"                    # (read when babe_amd.testing.blind_bwe_sampler is imported, below)
     import __graft_entry__ as ge
     ge.build()
     from babe_amd import _lib
@@ -527,6 +533,9 @@ def main():
                        "host_cpus_rank0": (f"pinned to {len(pinned)} CPUs ({pinned[0]}..{pinned[-1]})" if pinned else "unpinned"),
                        "hip_graphs": "none: eager launch loop, no host sync inside a step (the opt-in graph replay of rounds 2-4 "
                                      "measured 2.129 vs 2.140 audio-sec/s on this command and was removed in round 5)",
+                       "sequencer": ("Python: ~1200 C-ABI calls per evaluation (--no-eval-c / BABE_EVAL_C=0)"
+                                     if (a.no_eval_c or os.environ.get("BABE_EVAL_C", "1") != "1" or a.precision != "f32") else
+                                     "library: one babe_score_eval call per evaluation from Python (the product default)"),
                        "headline": a.T == 35 and a.precision == "f32" and C_ == 1},
             "per_gpu_realtime_factor": round(value / world, 5),
             "output_finite": finite,

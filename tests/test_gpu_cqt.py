@@ -140,9 +140,9 @@ def test_library_plan_equals_the_python_sequenced_transform(fs, L, monkeypatch):
     float64 ulp (tests/test_cqt_plan_cpu.py), i.e. a 1-ulp float32 difference in < 1e-4 of the table entries: bar 1e-6 relative;
     fwd reads no table (analytic window) and must be bit-identical."""
     from babe_amd.cqt import CQT_nsgt
-    monkeypatch.delenv("BABE_CQT_C", raising=False)          # (tools/measure_round.sh runs this file with the switch on as well)
+    monkeypatch.setenv("BABE_CQT_C", "0")                    # this class sequencing the kernels from the numpy design
     py = CQT_nsgt(7, 64, "oct", ("kaiser", 1), fs, L, device="cuda")
-    monkeypatch.setenv("BABE_CQT_C", "1")
+    monkeypatch.setenv("BABE_CQT_C", "1")                    # the library's plan (the default)
     cc = CQT_nsgt(7, 64, "oct", ("kaiser", 1), fs, L, device="cuda")
     monkeypatch.delenv("BABE_CQT_C")
     assert cc._plan and not py._plan

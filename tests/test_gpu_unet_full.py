@@ -347,3 +347,28 @@ def test_full_size_blind_sampler_bf16_bar():
         assert e < 5e-2
     print(f"full-size bf16 sampler: RMS err {rms_err(x, s['x']):.2e}, rel {rel(x, s['x']):.2e}")
     assert rms_err(x, s["x"]) < 5e-3
+
+
+def test_full_size_blind_sampler_on_the_library_evaluation(monkeypatch):
+    """The same golden with every score evaluation as ONE library call (babe_score_eval on the UNet and CQT plans, BABE_EVAL_C=1:
+    the non-Python host's path) at the benchmark's real size: bit-identical to the Python-sequenced run on the library's CQT plan
+    (same kernels, same order), and therefore inside the same bars against the reference."""
+    import babe_amd.testing.blind_bwe_sampler as bs
+    s = load("sampler_full_368368.npz")
+    L, T = int(s["L"]), int(s["T"])
+    monkeypatch.setenv("BABE_CQT_C", "1")
+    net = full_net(L)
+    smp = _full_size_sampler(net, s)
+    outs = {}
+    for mode in (False, True):
+        monkeypatch.setattr(bs, "EVAL_C", mode)
+        it = iter(_noises_full(s, 2))
+        smp._randn = lambda shape, device: next(it).to(device)
+        x, fp = smp.predict_blind_bwe(s["y"].repeat(2, 1).cuda())
+        torch.cuda.synchronize()
+        outs[mode] = (x.clone(), fp.clone())
+    assert smp._ceval, "the library path did not run"
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])
+    e_rms, e_rel = rms_err(outs[True][0][0:1], s["x"]), rel(outs[True][0][0:1], s["x"])
+    print(f"full-size sampler, one C call per evaluation: RMS err {e_rms:.2e}, rel {e_rel:.2e}")
+    assert e_rms < 1e-3 and e_rel < 5e-3

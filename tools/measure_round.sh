@@ -9,8 +9,8 @@ cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 python3 -m pytest tests -m gpu -q -s > $out/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $out/gpu_tests.log
 # the library-side UNet sequencer must not rot: the network / sampler parity files once more with BABE_UNET_C=1
 BABE_UNET_C=1 python3 -m pytest tests/test_gpu_unet_c.py tests/test_gpu_unet_full.py tests/test_gpu_sampler.py -m gpu -q > $out/gpu_tests_unet_c.log 2>&1; echo "pytest rc=$?" >> $out/gpu_tests_unet_c.log
-# ... and the library-side CQT plan + whole score evaluation (round 6): the sampler parity files with every evaluation as ONE C call
-BABE_EVAL_C=1 BABE_CQT_C=1 python3 -m pytest tests/test_gpu_sampler.py tests/test_gpu_cqt.py tests/test_gpu_eval_c.py -m gpu -q > $out/gpu_tests_eval_c.log 2>&1; echo "pytest rc=$?" >> $out/gpu_tests_eval_c.log
+# ... since round 6 the library-side CQT plan + whole score evaluation are the DEFAULT: the Python sequencers must not rot either
+BABE_EVAL_C=0 BABE_CQT_C=0 python3 -m pytest tests/test_gpu_sampler.py tests/test_gpu_cqt.py tests/test_gpu_eval_c.py tests/test_gpu_flows.py -m gpu -q > $out/gpu_tests_python_sequencer.log 2>&1; echo "pytest rc=$?" >> $out/gpu_tests_python_sequencer.log
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2> $out/bench.err
 python3 tools/overlap_timeline.py > $out/overlap.txt 2> $out/overlap.err
 python3 tools/conv_shapes_bench.py > $out/conv_shapes_fwd.txt 2>&1
