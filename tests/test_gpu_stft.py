@@ -137,3 +137,36 @@ def test_filter_fit_vs_golden(ci, kern):
     nit = st.filter_fit(stats, p, make_fit_cfg(fcmax=22050, kernel=kern))
     ref = g[f"fit{ci}_final"]
     assert torch.allclose(p[0, 0].cpu(), ref[0], rtol=1e-2) and torch.allclose(p[0, 1].cpu(), ref[1], atol=0.5), (p, ref, nit)
+
+
+@pytest.mark.parametrize("K,shared", [(1, True), (3, False), (5, True)])
+def test_filter_loss_grad_vs_oracle_autograd(K, shared):
+    """babe_filter_loss_grad (round 6): the fit objective ||w (|X| H - |Y|)|| and its gradient w.r.t. every (fc_j, A_j), one launch
+    for P parameter sets over shared or per-set statistics, against autograd through the oracle's design_filter / mag_loss
+    (utils/blind_bwe_utils.py:82-119, 250-296; testing/blind_bwe_sampler.py:523-533)."""
+    from babe_amd.stft import STFTOps, make_fit_cfg
+    fs, L, P = 44100, 30000, 4
+    g = torch.Generator().manual_seed(70 + K)
+    Bx = 1 if shared else P
+    x = 0.1 * torch.randn(Bx, L, generator=g)
+    st = STFTOps(4096, L, fs, "cuda")
+    f = U.bin_freqs(4096, fs)
+    y = U.apply_filter(x, U.design_filter(torch.tensor([2500.0]), torch.tensor([-30.0]), f), 4096)
+    fcs = torch.sort(800.0 + 9000.0 * torch.rand(P, K, generator=g), dim=1).values
+    As = -torch.sort(5.0 + 40.0 * torch.rand(P, K, generator=g), dim=1).values
+    params = torch.stack([fcs, As], 1).contiguous()                           # [P, 2, K]
+    stats = st.mag_stats(st.stft(x.cuda()), st.stft(y.cuda()), shared=shared)
+    assert stats.shape[0] == (1 if shared else P)
+    lg = st.filter_loss_grad(stats, params.cuda(), make_fit_cfg()).cpu()
+    assert lg.shape == (P, 1 + 2 * K)
+    Xm, Ym = U.stft(x, 4096).abs(), U.stft(y, 4096).abs()
+    w = U.freq_weight(Xm.shape[1], "sqrt")
+    for p in range(P):
+        q = params[p].clone().requires_grad_(True)
+        sl = slice(None) if shared else slice(p, p + 1)
+        loss = U.mag_loss(Xm[sl], Ym[sl], U.design_filter(q[0], q[1], f), w)
+        gq, = torch.autograd.grad(loss, q)
+        assert abs(float(lg[p, 0]) - float(loss)) < 2e-5 * float(loss), (p, float(lg[p, 0]), float(loss))
+        ref = torch.cat([gq[0], gq[1]])
+        err = float((lg[p, 1:] - ref).abs().max() / (ref.abs().max() + 1e-12))
+        assert err < 5e-4, (p, err, lg[p, 1:], ref)
