@@ -676,10 +676,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
 #define Z_WLOAD(GN)                                                                                                          \
     if (!(W85_ABL & 4)) aw[(GN) % RD] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo, sW + ((GN) % 3) * 1024, 0)); \
     if constexpr ((GN) % 3 == 2) w_next();
+#if W85_ABL & 8192        // (timing probe: waves 4, 5 of the 96-channel tile do half their MFMAs - the balance a K-split would give)
+#define Z_SKIP(GN) (NW == 6 && wave >= 4 && (GN) >= 12)
+#else
+#define Z_SKIP(GN) false
+#endif
 #define Z_G(GN)                                                        \
     Z_READ(((GN) + 1) & 1, Xs, ((GN) + 1) / 3, ((GN) + 1) % 3)         \
     Y_FENCE                                                            \
-    Z_MFMA((GN) & 1, GN)                                               \
+    if (!Z_SKIP(GN)) Z_MFMA((GN) & 1, GN)                              \
     Y_FENCE                                                            \
     Z_WLOAD(GN)                                                        \
     Y_FENCE
