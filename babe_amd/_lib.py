@@ -27,6 +27,8 @@ class ConvArgs(C.Structure):
         ("alpha", C.c_float), ("rbeta", C.c_float),
         ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("F", C.c_int), ("T", C.c_int),
         ("KH", C.c_int), ("KW", C.c_int), ("dil", C.c_int),
+        # optional reduction fused into the F(4,5) kernels' epilogue (include/babe_hip.h; zero = off)
+        ("stat_mode", C.c_int), ("stat_cg", C.c_int), ("stat_x", C.c_void_p), ("stat_scale", C.c_void_p), ("stat_part", C.c_void_p),
     ]
 
 
@@ -51,6 +53,7 @@ _SIGS = {
     "babe_conv2d_wino85": [C.POINTER(ConvArgs), _P, _P],
     "babe_conv2d_wino85_supported": [C.POINTER(ConvArgs)],
     "babe_conv2d_wino85_preferred": [C.POINTER(ConvArgs)],
+    "babe_conv2d_wino85_stat_slots": [C.POINTER(ConvArgs)],
     "babe_conv_pack_weights_wino45": [_P, _P, _I, _I, _I, _I, _I, _P],
     "babe_conv_pack_weights_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "babe_gn_partial": [_P, _P, _I, _I, _L, _I, _P],

@@ -84,6 +84,7 @@ __device__ __forceinline__ void conv11p_epilogue(const babe_conv_args& a, f32x16
     // The residual of group g + 1 (one (row tile, column tile) pair = 16 values per lane) is loaded while group g is scaled and
     // stored: two groups of loads in flight per wave instead of one (the res-carrying layers - every VJP - are bound by this
     // epilogue: 16 loads x 256 B per wave in flight is about 4.4 TB/s over the chip, which is where they sat).
+    const float os_m = has_os ? a.alpha : 0.f, os_a = has_os ? 0.f : a.alpha;
     float rv[2][16];
     auto load_res = [&](int gidx, float (&dst)[16]) {
         const int nt = gidx / WP, wp = gidx % WP;
@@ -101,8 +102,10 @@ __device__ __forceinline__ void conv11p_epilogue(const babe_conv_args& a, f32x16
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int cl = nt * 32 + (r & 3) + 8 * (r >> 2);
-            os[r] = has_os ? __fmul_rn(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, (unsigned)(co0 + 4 * h + cl) * 4u, 0, 0)), a.alpha)
-                           : a.alpha;
+            // (unconditional: without output scales the descriptor has size 0 and the load returns 0.  Under `has_os ? load : alpha`
+            // the compiler put each of the 16 loads in its own branch with its own s_waitcnt vmcnt(0))
+            const float sv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, (unsigned)(co0 + 4 * h + cl) * 4u, 0, 0));
+            os[r] = __builtin_fmaf(sv, os_m, os_a);     // = sv * alpha with output scales, alpha without
         }
 #pragma unroll
         for (int wp = 0; wp < WP; ++wp) {

@@ -33,6 +33,7 @@
 #include "common.h"
 #include "../../include/babe_hip.h"
 #include "prof.h"
+#include "gelu.h"
 #include <atomic>
 #include <cstdlib>
 
@@ -150,26 +151,64 @@ __device__ __forceinline__ void w85_carry(f32x4 (&acc)[2][12]) {
         }
 }
 // output: rows r = 0..3 from (M5, M6, M0, M7) = acc[0][0..5], acc[0][6..11], acc[1][0..5], acc[1][6..11]; cot0 = the wave's first channel
+// tile / ntiles: this workgroup's index in the launch's list of (row quad, time tile) tiles of a batch item and the list's length -
+// the slot of the optional fused reduction (babe_conv_args::stat_mode, include/babe_hip.h)
 __device__ __forceinline__ void w85_epilogue(const babe_conv_args& a, const f32x4 (&acc)[2][12], int b, int cot0, int fa, int t0, int lk,
-                                             int l15) {
+                                             int l15, int tile, int ntiles) {
 #pragma clang fp contract(off)
     const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
     const int t = t0 + 4 * l15;
+    const int smode = a.stat_mode;                      // (kernel-uniform)
+    double ssum = 0.0;                                   // mode 2: sum over this lane's 4 channels x 4 rows x 4 steps
+    // Every load of the epilogue is unconditional (an out-of-range point reads the channel's first float4 and is masked at the
+    // store) and issued a row ahead of its use: with the loads under `if (pv)` each of the 16 (row, channel) steps waited out
+    // its own memory latency (s_waitcnt vmcnt(0) per step in the ISA).
+    // Offsets inside one batch element are 32-bit (babe_conv2d_wino85_supported bounds Cout * out_cs and Cout * res_cs).
+    float os[4] = {1.f, 1.f, 1.f, 1.f}, scx[4] = {0.f, 0.f, 0.f, 0.f};
+    const int co0 = cot0 + 4 * lk;
+    if (has_os) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) os[kk] = a.oscale[b * a.Cout + co0 + kk];
+    }
+    if (smode == 2) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) scx[kk] = a.stat_scale[b * a.Cout + co0 + kk];
+    }
+    float* const outb = a.out + (long)b * a.out_bs;
+    const int ocs = (int)a.out_cs;
+    // res and stat_x are never both given (the launcher rejects it): one staging array, two rows in flight
+    const float* const lsrc = smode == 2 ? a.stat_x + (long)b * a.out_bs : (has_res ? a.res + (long)b * a.res_bs : nullptr);
+    const int lcs = smode == 2 ? ocs : (int)a.res_cs;
+    const bool has_ld = lsrc != nullptr;
+    f32x4 ld[4][4];
+    bool pvr[4];
+    int spr[4];
 #pragma unroll
     for (int row = 0; row < 4; ++row) {
         const int f = fa + row * a.dil;
-        const bool pv = f < a.F && t < a.T;
-        const long sp = pv ? (long)f * a.T + t : 0;
+        pvr[row] = f < a.F && t < a.T;
+        spr[row] = pvr[row] ? f * a.T + t : 0;
+    }
+#pragma unroll
+    for (int row = 0; row < 4; ++row)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ld[row][kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_ld) {
+#pragma unroll
+        for (int row = 0; row < 2; ++row)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) ld[row][kk] = *reinterpret_cast<const f32x4*>(lsrc + ((co0 + kk) * lcs + spr[row]));
+    }
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const bool pv = pvr[row];
+        const int sp = spr[row];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int co = cot0 + 4 * lk + kk;
-            const float os = has_os ? a.oscale[b * a.Cout + co] : 1.f;
-            const f32x4 rr = (has_res && pv) ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)co * a.res_cs + sp)
-                                             : f32x4{0.f, 0.f, 0.f, 0.f};
             float m[6];
             if (W85_ABL & 4096) {                       // (no output transform: raw accumulators stored)
                 const f32x4 y = {acc[0][row][kk], acc[0][6 + row][kk], acc[1][row][kk], acc[1][6 + row][kk]};
-                if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
+                if (pv) *reinterpret_cast<f32x4*>(outb + ((co0 + kk) * ocs + sp)) = y;
                 continue;
             }
 #pragma unroll
@@ -180,15 +219,40 @@ __device__ __forceinline__ void w85_epilogue(const babe_conv_args& a, const f32x
             const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
             const float y0 = m[0] + s12 + s34, y1 = __builtin_fmaf(2.f, d34, d12), y2 = __builtin_fmaf(4.f, s34, s12),
                         y3 = __builtin_fmaf(8.f, d34, d12) + m[5];
-            const float sc = a.alpha * os;
+            const float sc = a.alpha * os[kk];
+            const f32x4 r4 = smode == 2 ? f32x4{0.f, 0.f, 0.f, 0.f} : ld[row][kk];
             f32x4 y;
-            y[0] = __builtin_fmaf(y0, sc, a.rbeta * rr[0]);
-            y[1] = __builtin_fmaf(y1, sc, a.rbeta * rr[1]);
-            y[2] = __builtin_fmaf(y2, sc, a.rbeta * rr[2]);
-            y[3] = __builtin_fmaf(y3, sc, a.rbeta * rr[3]);
+            y[0] = __builtin_fmaf(y0, sc, a.rbeta * r4[0]);
+            y[1] = __builtin_fmaf(y1, sc, a.rbeta * r4[1]);
+            y[2] = __builtin_fmaf(y2, sc, a.rbeta * r4[2]);
+            y[3] = __builtin_fmaf(y3, sc, a.rbeta * r4[3]);
             if (W85_ABL & 2048) {                       // (no stores: the arithmetic stays)
                 if (y[0] == 12345.f && y[1] == 5.f) *reinterpret_cast<f32x4*>(a.out) = y;
-            } else if (pv) *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)co * a.out_cs + sp) = y;
+            } else if (pv) *reinterpret_cast<f32x4*>(outb + ((co0 + kk) * ocs + sp)) = y;
+            if (smode == 2 && pv) {
+                // babe_gn_bwd_partial's term for these four outputs (csrc/norm.hip: dv = da * gelu'(x * sc) in float, dv * x summed
+                // in double, times sc per channel): y IS the da this conv writes
+                const f32x4 x4 = ld[row][kk];
+                double cs = 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cs += (double)(y[e] * babe_gelu::gelu_grad_f(x4[e] * scx[kk])) * (double)x4[e];
+                ssum += (double)scx[kk] * cs;
+            }
+        }
+        if (row < 2 && has_ld) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) ld[row + 2][kk] = *reinterpret_cast<const f32x4*>(lsrc + ((co0 + kk) * lcs + spr[row + 2]));
+        }
+    }
+    if (smode == 2) {
+        // the 16 lanes of a row (same lk) hold the same channel quad: sum them, lane 0 of the row writes the quad's slot
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) ssum += __shfl_xor(ssum, o, 16);
+        if (l15 == 0) {
+            const int gq = a.stat_cg >> 2, cq = (cot0 >> 2) + lk;            // channel quads per group; this row's quad
+            const int g = cq / gq, q = cq - g * gq;
+            const long S = (long)ntiles * gq;
+            a.stat_part[((long)b * (a.Cout / a.stat_cg) + g) * S + (long)tile * gq + q] = ssum;
         }
     }
 }
@@ -475,7 +539,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino85_kernel(babe_conv_args a, W
         if (sacc[0] == 12345.f) *reinterpret_cast<f32x4*>(a.out) = sacc;
         return;
     }
-    w85_epilogue(a, acc, b, co0 + wave * 16, fa, t0, lk, l15);
+    w85_epilogue(a, acc, b, co0 + wave * 16, fa, t0, lk, l15, g.xcd ? bx : Q * g.tiles_t + tile_t, g.tiles_t * nQ);
 #endif
 }
 
@@ -718,7 +782,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
 #undef Z_WLOAD
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
 
-    w85_epilogue(a, acc, b, co0 + wave * 16, fa, t0, lk, l15);
+    w85_epilogue(a, acc, b, co0 + wave * 16, fa, t0, lk, l15, g.xcd ? bx : Q * g.tiles_t + tile_t, g.tiles_t * nQ);
 #endif
 }
 
@@ -817,9 +881,17 @@ extern "C" int babe_conv2d_wino85_supported(const babe_conv_args* ap) {
     if (!al16(a.out) || a.out_bs % 4 || a.out_cs % 4) return 0;
     if (a.res && (!al16(a.res) || a.res_bs % 4 || a.res_cs % 4)) return 0;
     const long lim = 0x3fffffffL / 4;
-    if ((long)a.Cin * a.in_cs >= lim || (long)a.F * a.T >= lim) return 0;
+    if ((long)a.Cin * a.in_cs >= lim || (long)a.F * a.T >= lim || (long)a.Cout * a.out_cs >= lim ||
+        (a.res && (long)a.Cout * a.res_cs >= lim))
+        return 0;
     if (48L * a.Cin * a.Cout * 4 >= 0x7fffffffL) return 0;
     return 1;
+}
+
+extern "C" int babe_conv2d_wino85_stat_slots(const babe_conv_args* ap) {
+    if (!ap || ap->stat_cg < 4 || ap->stat_cg % 4 != 0 || ap->dil < 1 || ap->F < 1 || ap->T < 1) return 0;
+    const babe_conv_args& a = *ap;
+    return cdiv(a.T, 64) * a.dil * cdiv(cdiv(a.F, a.dil), 4) * (a.stat_cg / 4);
 }
 
 /* fraction of the row-quad x time slots of a launch that hold real outputs */
@@ -851,6 +923,11 @@ extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino8
     BABE_CHECK_ARG(ap && w_wino85, "conv2d_wino85: null args");
     BABE_CHECK_ARG(babe_conv2d_wino85_supported(ap), "conv2d_wino85: unsupported problem");
     const babe_conv_args& a = *ap;
+    if (a.stat_mode) {
+        BABE_CHECK_ARG(a.stat_mode == 2 && a.stat_part && a.stat_x && a.stat_scale && a.stat_cg >= 4 && a.stat_cg % 4 == 0 &&
+                           a.Cout % a.stat_cg == 0 && ((uintptr_t)a.stat_x & 15) == 0 && a.res == nullptr,
+                       "conv2d_wino85: fused reduction: mode %d, group size %d (Cout %d)", a.stat_mode, a.stat_cg, a.Cout);
+    }
     Wino85Geom g;
     g.CinP = a.Cin;
     g.CoutP = a.Cout;

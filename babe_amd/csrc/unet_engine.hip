@@ -18,7 +18,8 @@
 
 /* out = alpha*conv(in[,in2]; W)*oscale + rbeta*res with the kernel chosen by the library (what babe_amd/ops.py::conv2d did in
  * Python): few-output-channel vector kernel, nested Winograd F(2,5)xF(4,3) where its tiles are full, F(4,3), F(2,3), direct /
- * pipelined (1,1).  The caller fills every field of *a except w_packed, Cin, Cout, KH, KW (taken from pc and transpose). */
+ * pipelined (1,1).  The caller fills every field of *a except w_packed, Cin, Cout, KH, KW (taken from pc and transpose).  A requested
+ * fused reduction (a->stat_mode) is formed only by the F(4,5) kernels: on return a->stat_mode is 0 if it was NOT produced. */
 extern "C" int babe_conv2d_auto(babe_conv_args* a, const babe_packed_conv* pc, int transpose, void* stream) {
     BABE_CHECK_ARG(a && pc, "conv2d_auto: null arguments");
     a->Cin = transpose ? pc->Cout : pc->Cin;
@@ -30,13 +31,18 @@ extern "C" int babe_conv2d_auto(babe_conv_args* a, const babe_packed_conv* pc, i
     if (!a->in2) a->cin_split = a->Cin;
     if (pc->splits) {
         a->w_packed = nullptr;
+        a->stat_mode = 0;
         return babe_conv2d_bf16(a, wq, pc->splits, stream);
     }
     a->w_packed = (const float*)wq;
     const float* w45 = transpose ? pc->bwd_wino45 : pc->fwd_wino45;
-    if (pc->w_raw && a->Cout <= 4 && babe_conv2d_fewco_supported(a)) return babe_conv2d_fewco(a, pc->w_raw, transpose, stream);
+    if (pc->w_raw && a->Cout <= 4 && babe_conv2d_fewco_supported(a)) {
+        a->stat_mode = 0;
+        return babe_conv2d_fewco(a, pc->w_raw, transpose, stream);
+    }
     const float* w85 = transpose ? pc->bwd_wino85 : pc->fwd_wino85;
     if (w85 && !a->in2 && babe_conv2d_wino85_preferred(a)) return babe_conv2d_wino85(a, w85, stream);
+    a->stat_mode = 0;                  // only the F(4,5) kernels form the fused reduction: tell the caller it was not produced
     if (w45 && babe_conv2d_wino45_preferred(a)) return babe_conv2d_wino45(a, w45, stream);
     if (pc->fwd_wino4 && babe_conv2d_wino4_supported(a)) return babe_conv2d_wino4(a, transpose ? pc->bwd_wino4 : pc->fwd_wino4, stream);
     if (pc->fwd_wino && babe_conv2d_wino_supported(a)) return babe_conv2d_wino(a, transpose ? pc->bwd_wino : pc->fwd_wino, stream);
@@ -213,13 +219,38 @@ struct Ctx {
         else axpby2(z, x, out, RS2, RS2);
         return out;
     }
-    void gn_bwd(const Saved& sv, const View& da, const View& gy, const View& gx, float rbeta, const View* acc = nullptr) {
+    // the transposed conv of dilation layer d, with the GroupNorm-VJP partial sums formed in its epilogue when it takes the F(4,5)
+    // kernel (unet_engine.py: ops.conv2d(..., vjp_stat=)): returns the slot count S (0: not fused) and the buffer in *part
+    int conv_vjp(const View& src, const babe_unet_block& blk, int d, const View& da, const Saved& sv, double** part) {
+        const View& z = sv.z;
+        const int dil = blk.k53 ? (1 << d) : 1, cg = z.C / G_GROUPS;
+        const int Sf = ((z.T + 63) / 64) * dil * ((((z.F + dil - 1) / dil) + 3) / 4) * (cg / 4);
+        const long n = (long)cg * z.F * z.T;
+        const int Sp = splits(n);
+        *part = reinterpret_cast<double*>(alloc((size_t)B() * G_GROUPS * (Sf > Sp ? Sf : Sp) * 2));     // (floats: 2 per double)
+        if (dry() || err) return 0;
+        babe_conv_args a;
+        memset(&a, 0, sizeof a);
+        a.in = src.p; a.in_bs = src.bs; a.in_cs = src.cs;
+        a.out = da.p; a.out_bs = da.bs; a.out_cs = da.cs;
+        a.in_scale = sv.gate; a.alpha = RS2; a.rbeta = 0.f;
+        a.B = B(); a.F = src.F; a.T = src.T; a.dil = dil;
+        if (fuse_gn() && blk.k53 && cg % 4 == 0 && z.dense() && da.dense()) {
+            a.stat_mode = 2; a.stat_cg = cg; a.stat_x = z.p; a.stat_scale = sv.scale; a.stat_part = *part;
+        }
+        ck(babe_conv2d_auto(&a, &blk.H[d], 1, st));
+        return a.stat_mode == 2 ? Sf : 0;
+    }
+    static bool fuse_gn() {
+        static const bool on = [] { const char* e = getenv("BABE_FUSE_GN"); return e && atoi(e) != 0; }();   // (off by default: ops.py FUSE_GN)
+        return on;
+    }
+    void gn_bwd(const Saved& sv, const View& da, const View& gy, const View& gx, float rbeta, const View* acc, double* part, int Sf) {
         const View& z = sv.z;
         const long n = (long)(z.C / G_GROUPS) * z.F * z.T;
-        const int Sp = splits(n);
-        double* part = reinterpret_cast<double*>(alloc((size_t)B() * G_GROUPS * Sp * 2));
+        const int Sp = Sf > 0 ? Sf : splits(n);
         if (dry() || err) return;
-        ck(babe_gn_bwd_partial(z.p, da.p, sv.scale, part, B(), z.C, G_GROUPS, (long)z.F * z.T, Sp, st));
+        if (Sf <= 0) ck(babe_gn_bwd_partial(z.p, da.p, sv.scale, part, B(), z.C, G_GROUPS, (long)z.F * z.T, Sp, st));
         if (acc)          // the block's tail merged in: gx = RS2*acc + RS2*(this layer's gradient)
             ck(babe_gn_bwd_apply_merge(z.p, da.p, gy.p, sv.scale, sv.stats, part, gx.p, rbeta, B(), z.C, G_GROUPS, (long)z.F * z.T, Sp, GN_EPS, st,
                                        acc->p, RS2, RS2));
@@ -238,12 +269,13 @@ struct Ctx {
             View src = g_out;
             const bool merged = g_in.dense() && al16(g_in) && al16(g_out);
             for (int d = blk.nd - 1; d >= 0; --d) {
-                conv(src, blk.H[d], da, blk.k53 ? (1 << d) : 1, true, nullptr, nullptr, saved[d].gate, nullptr, RS2, 0.f);
+                double* part;
+                const int Sf = conv_vjp(src, blk, d, da, saved[d], &part);
                 if (d == 0 && merged) {
-                    gn_bwd(saved[d], da, src, g_in, RS2, &g_out);
+                    gn_bwd(saved[d], da, src, g_in, RS2, &g_out, part, Sf);
                 } else {
                     if (!gz.p && !gz.C) gz = buf(N, Fq, T);
-                    gn_bwd(saved[d], da, src, gz, RS2);
+                    gn_bwd(saved[d], da, src, gz, RS2, nullptr, part, Sf);
                     src = gz;
                 }
             }
@@ -266,8 +298,9 @@ struct Ctx {
         }
         View da = da_view();
         for (int d = blk.nd - 1; d >= 0; --d) {
-            conv(gz, blk.H[d], da, blk.k53 ? (1 << d) : 1, true, nullptr, nullptr, saved[d].gate, nullptr, RS2, 0.f);
-            gn_bwd(saved[d], da, gz, gz, RS2);
+            double* part;
+            const int Sf = conv_vjp(gz, blk, d, da, saved[d], &part);
+            gn_bwd(saved[d], da, gz, gz, RS2, nullptr, part, Sf);
         }
         if (blk.proj_in.Cout) conv(gz, blk.proj_in, g_in, 1, true, nullptr, &g_in, nullptr, nullptr, c, 1.f);
         else axpby(gz, g_in, c, 1.f);

@@ -196,14 +196,14 @@ class UnetEngine:
             merged = g_in.is_contiguous() and MERGE_TAIL
             for d in reversed(range(blk.nd)):
                 z, stats, scale, gate = blk.saved[d]
-                ops.conv2d(src, blk.H[d], da, dil=blk.dil(d), transpose=True, in_scale=gate, alpha=RS2)
+                fs = ops.conv2d(src, blk.H[d], da, dil=blk.dil(d), transpose=True, in_scale=gate, alpha=RS2, vjp_stat=(z, scale, N // 8))
                 if d == 0 and merged:
                     # the last layer's VJP pass writes g_in = RS2*g_out + RS2*gz itself (gz is never stored)
-                    ops.gn_bwd(z, da, src, scale, stats, g_in, RS2, merge=(g_out, RS2, RS2))
+                    ops.gn_bwd(z, da, src, scale, stats, g_in, RS2, merge=(g_out, RS2, RS2), fused=fs)
                 else:
                     if gz is None:
                         gz = self.buf(B, N, Fq, T)
-                    ops.gn_bwd(z, da, src, scale, stats, gz, RS2)
+                    ops.gn_bwd(z, da, src, scale, stats, gz, RS2, fused=fs)
                     src = gz
             if not merged:
                 ops.axpby2(g_out, gz, g_in, RS2, RS2)
@@ -226,8 +226,8 @@ class UnetEngine:
         da = self.scratch("a", B * N * Fq * T).view(B, N, Fq, T)
         for d in reversed(range(blk.nd)):
             z, stats, scale, gate = blk.saved[d]
-            ops.conv2d(gz, blk.H[d], da, dil=blk.dil(d), transpose=True, in_scale=gate, alpha=RS2)
-            ops.gn_bwd(z, da, gz, scale, stats, gz, RS2)
+            fs = ops.conv2d(gz, blk.H[d], da, dil=blk.dil(d), transpose=True, in_scale=gate, alpha=RS2, vjp_stat=(z, scale, N // 8))
+            ops.gn_bwd(z, da, gz, scale, stats, gz, RS2, fused=fs)
         if blk.proj_in is not None:
             ops.conv2d(gz, blk.proj_in, g_in, transpose=True, res=g_in, alpha=c, rbeta=1.0)
         else:

@@ -123,11 +123,20 @@ class PackedConv:
                 check(L.babe_conv_pack_weights_wino85(ptr(w), ptr(self.bwd_wino85), self.Cout, self.Cin, self.KH, self.KW, 1, stream()), "pack_wino85")
 
 
+# GroupNorm-VJP partial sums formed in the F(4,5) transposed conv's epilogue instead of babe_gn_bwd_partial's own pass: OFF by
+# default - measured 0.5 % slower than the separate pass (profiles/r06_gn_fusion_experiment.txt: the GELU' arithmetic runs on the
+# multiply waves with nothing to overlap it); BABE_FUSE_GN=1 turns it on (tests/test_gpu_ops.py keeps it parity-checked)
+FUSE_GN = os.environ.get("BABE_FUSE_GN", "0") != "0"
+
+
 def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=None, oscale=None, alpha=1.0, rbeta=0.0,
-           force_nested=False, force_f45=False):
+           force_nested=False, force_f45=False, vjp_stat=None):
     """out = alpha*conv(x[,x2]; W)*oscale + rbeta*res   (transpose=True: input-VJP weights).
     force_nested: take the nested-Winograd F(2,5) x F(4,3) kernel whenever it CAN run the problem (tests), not only when it is
-    preferred; force_f45: the same for the F(4,5) x F(4,3) kernel."""
+    preferred; force_f45: the same for the F(4,5) x F(4,3) kernel.
+    vjp_stat=(z, scale, cg): if the launch takes the F(4,5) kernel, its epilogue also forms the partial sums of the GroupNorm /
+    FiLM / GELU input-VJP for the gradient `out` it writes (z: the layer's saved input, dense like out; scale [B,C]; cg channels
+    per group) and (part, S) is RETURNED for gn_bwd(part=, S=); otherwise None is returned and gn_bwd runs its own pass."""
     a = ConvArgs()
     B, C1, F, T = x.shape
     Cin = pc.Cout if transpose else pc.Cin
@@ -164,7 +173,17 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
         check(lib().babe_conv2d_fewco(C.byref(a), ptr(pc.w_raw), int(transpose), stream()), "conv2d_fewco")
     elif getattr(pc, "bwd_wino85" if transpose else "fwd_wino85", None) is not None and x2 is None and not force_nested and (
             lib().babe_conv2d_wino85_supported(C.byref(a)) if force_f45 else lib().babe_conv2d_wino85_preferred(C.byref(a))):
+        fused = None
+        if vjp_stat is not None and FUSE_GN:
+            z, scale, cg = vjp_stat
+            assert z.is_contiguous() and out.is_contiguous() and z.shape == out.shape and scale.is_contiguous()
+            a.stat_mode, a.stat_cg, a.stat_x, a.stat_scale = 2, cg, ptr(z), ptr(scale)
+            S = lib().babe_conv2d_wino85_stat_slots(C.byref(a))
+            part = torch.empty(B * (Cout // cg) * S, device=x.device, dtype=torch.float64)
+            a.stat_part = ptr(part)
+            fused = (part, S)
         check(lib().babe_conv2d_wino85(C.byref(a), ptr(pc.bwd_wino85 if transpose else pc.fwd_wino85), stream()), "conv2d_wino85")
+        return fused if vjp_stat is not None else out
     elif getattr(pc, "bwd_wino45" if transpose else "fwd_wino45", None) is not None and (lib().babe_conv2d_wino45_supported(C.byref(a)) if force_nested
                                                           else lib().babe_conv2d_wino45_preferred(C.byref(a))):
         check(lib().babe_conv2d_wino45(C.byref(a), ptr(pc.bwd_wino45 if transpose else pc.fwd_wino45), stream()), "conv2d_wino45")
@@ -174,7 +193,7 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
         check(lib().babe_conv2d_wino(C.byref(a), ptr(pc.bwd_wino if transpose else pc.fwd_wino), stream()), "conv2d_wino")
     else:
         check(lib().babe_conv2d_nt(C.byref(a), pc.nt, stream()), "conv2d")
-    return out
+    return None if vjp_stat is not None else out
 
 
 def _splits(n, B, G):
@@ -306,16 +325,20 @@ def conv2d_units(au, pc, out, Cin, dil=1, res=None, oscale=None, alpha=1.0, rbet
     return out
 
 
-def gn_bwd(x, da, gy, scale, stats, gx, rbeta, G=8, eps=1e-7, merge=None):
+def gn_bwd(x, da, gy, scale, stats, gx, rbeta, G=8, eps=1e-7, merge=None, fused=None):
     """gx = rbeta*gy + GN/FiLM/GELU input-VJP of da (gx may alias gy; da is only read).
-    merge=(acc, ca, cb): gx = ca*acc + cb*(that result) in the same pass (a block's VJP tail, babe_gn_bwd_apply_merge)."""
+    merge=(acc, ca, cb): gx = ca*acc + cb*(that result) in the same pass (a block's VJP tail, babe_gn_bwd_apply_merge).
+    fused=(part, S): the partial sums already formed by the conv that wrote da (conv2d(..., vjp_stat=)): no babe_gn_bwd_partial."""
     B, Cc, F, T = x.shape
     assert x.is_contiguous() and da.is_contiguous() and gx.is_contiguous() and (gy is None or gy.is_contiguous())
     n = (Cc // G) * F * T
-    S = _splits(n, B, G)
-    part = torch.empty(B * G * S, device=x.device, dtype=torch.float64)
     L = lib()
-    check(L.babe_gn_bwd_partial(ptr(x), ptr(da), ptr(scale), ptr(part), B, Cc, G, F * T, S, stream()), "gn_bwd_partial")
+    if fused is not None:
+        part, S = fused
+    else:
+        S = _splits(n, B, G)
+        part = torch.empty(B * G * S, device=x.device, dtype=torch.float64)
+        check(L.babe_gn_bwd_partial(ptr(x), ptr(da), ptr(scale), ptr(part), B, Cc, G, F * T, S, stream()), "gn_bwd_partial")
     if merge is not None:
         acc, ca, cb = merge
         assert acc.is_contiguous() and acc.shape == x.shape

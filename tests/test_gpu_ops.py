@@ -826,3 +826,45 @@ def test_conv2d_f45_dispatch_rule_and_tile_order(ops):
     dispatch_counts(reset=True)
     ops.conv2d(xa, pc, out, dil=4, x2=xb)
     assert dispatch_counts()["conv53_wino85"] == 0
+
+
+def test_f45_epilogue_forms_the_groupnorm_vjp_partial_sums(ops, monkeypatch):
+    """(Opt-in, BABE_FUSE_GN=1: measured 0.5 % slower than the separate pass - profiles/r06_gn_fusion_experiment.txt.)  Round 6: the transposed (5,3) conv that writes da also forms, in its epilogue, the per-group sums S_g = sum da * u * gelu'(u)
+    (u = scale * z) that babe_gn_bwd_partial would re-read z and da for (babe_conv_args::stat_mode 2) - for the 128- (12- and 8-wave),
+    96- and 64-channel tile forms, ragged time tiles and partly filled row quads included: group totals against the stand-alone pass
+    (both sum in double, in different orders), da bit-identical with and without the reduction, and gn_bwd on either set of partial
+    sums to float rounding."""
+    from babe_amd._lib import dispatch_counts, lib
+    monkeypatch.setattr(ops, "FUSE_GN", True)
+    for Cc, Fq, T, dil, waves in ((128, 48, 128, 2, 12), (128, 48, 128, 2, 8), (96, 40, 192, 1, 12), (64, 36, 100, 3, 12), (256, 28, 64, 4, 12)):
+        assert lib().babe_conv2d_wino85_set_waves(waves) == 0
+        g = torch.Generator().manual_seed(Cc + Fq + T)
+        B = 2
+        z = torch.randn(B, Cc, Fq, T, generator=g).cuda()
+        src = torch.randn(B, Cc, Fq, T, generator=g).cuda()
+        w = (torch.randn(Cc, Cc, 5, 3, generator=g) / math.sqrt(Cc * 15)).cuda()
+        gate = torch.randn(B, Cc, generator=g).cuda()
+        scale = (0.5 + torch.rand(B, Cc, generator=g)).cuda()
+        pc = ops.PackedConv(w)
+        da0, da1 = torch.empty_like(z), torch.empty_like(z)
+        dispatch_counts(reset=True)
+        ops.conv2d(src, pc, da0, dil=dil, transpose=True, in_scale=gate, alpha=0.7, force_f45=True)
+        fs = ops.conv2d(src, pc, da1, dil=dil, transpose=True, in_scale=gate, alpha=0.7, force_f45=True, vjp_stat=(z, scale, Cc // 8))
+        assert dispatch_counts()["conv53_wino85"] == 2 and fs is not None
+        assert torch.equal(da0, da1)
+        part, S = fs
+        got = part.view(B, 8, S).sum(-1)
+        n = (Cc // 8) * Fq * T
+        Sp = ops._splits(n, B, 8)
+        ref = torch.empty(B * 8 * Sp, device="cuda", dtype=torch.float64)
+        from babe_amd._lib import check, ptr, stream
+        check(lib().babe_gn_bwd_partial(ptr(z), ptr(da0), ptr(scale), ptr(ref), B, Cc, 8, Fq * T, Sp, stream()), "gn_bwd_partial")
+        want = ref.view(B, 8, Sp).sum(-1)
+        err = float(((got - want).abs() / (want.abs() + 1e-9 * want.abs().max())).max())
+        assert err < 1e-9, (Cc, waves, err)
+        stats = torch.stack([torch.zeros(B, 8), torch.ones(B, 8), torch.ones(B, 8)], -1).cuda().contiguous()
+        gx0, gx1 = torch.empty_like(z), torch.empty_like(z)
+        ops.gn_bwd(z, da0, src, scale, stats, gx0, 0.7)
+        ops.gn_bwd(z, da0, src, scale, stats, gx1, 0.7, fused=fs)
+        assert float((gx0 - gx1).abs().max() / gx0.abs().max()) < 1e-6
+    assert lib().babe_conv2d_wino85_set_waves(12) == 0
