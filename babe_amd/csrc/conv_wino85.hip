@@ -159,7 +159,7 @@ __device__ __forceinline__ void w85_epilogue(const babe_conv_args& a, const f32x
     const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
     const int t = t0 + 4 * l15;
     const int smode = a.stat_mode;                      // (kernel-uniform)
-    double ssum = 0.0;                                   // mode 2: sum over this lane's 4 channels x 4 rows x 4 steps
+    double ssum = 0.0, ssq = 0.0;                        // sums over this lane's 4 channels x 4 rows x 4 steps (mode 1: y, y^2; mode 2: ssum)
     // Every load of the epilogue is unconditional (an out-of-range point reads the channel's first float4 and is masked at the
     // store) and issued a row ahead of its use: with the loads under `if (pv)` each of the 16 (row, channel) steps waited out
     // its own memory latency (s_waitcnt vmcnt(0) per step in the ISA).
@@ -229,6 +229,15 @@ __device__ __forceinline__ void w85_epilogue(const babe_conv_args& a, const f32x
             if (W85_ABL & 2048) {                       // (no stores: the arithmetic stays)
                 if (y[0] == 12345.f && y[1] == 5.f) *reinterpret_cast<f32x4*>(a.out) = y;
             } else if (pv) *reinterpret_cast<f32x4*>(outb + ((co0 + kk) * ocs + sp)) = y;
+            if (smode == 1 && pv) {
+                // babe_gn_partial's sums of the output this conv writes (csrc/norm.hip: sum and sum of squares in double)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double v = (double)y[e];
+                    ssum += v;
+                    ssq += v * v;
+                }
+            }
             if (smode == 2 && pv) {
                 // babe_gn_bwd_partial's term for these four outputs (csrc/norm.hip: dv = da * gelu'(x * sc) in float, dv * x summed
                 // in double, times sc per channel): y IS the da this conv writes
@@ -244,15 +253,33 @@ __device__ __forceinline__ void w85_epilogue(const babe_conv_args& a, const f32x
             for (int kk = 0; kk < 4; ++kk) ld[row + 2][kk] = *reinterpret_cast<const f32x4*>(lsrc + ((co0 + kk) * lcs + spr[row + 2]));
         }
     }
-    if (smode == 2) {
-        // the 16 lanes of a row (same lk) hold the same channel quad: sum them, lane 0 of the row writes the quad's slot
+    if (smode) {
+        // The 16 lanes of a row (same lk) hold the same channel quad, the wave 16 consecutive channels: a slot = the largest run of
+        // channels (4, 8 or 16) that divides the group size, summed in the wave in a fixed order and written exactly once.
+        const int sg = (a.stat_cg & 15) == 0 ? 16 : ((a.stat_cg & 7) == 0 ? 8 : 4);
 #pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) ssum += __shfl_xor(ssum, o, 16);
-        if (l15 == 0) {
-            const int gq = a.stat_cg >> 2, cq = (cot0 >> 2) + lk;            // channel quads per group; this row's quad
-            const int g = cq / gq, q = cq - g * gq;
-            const long S = (long)ntiles * gq;
-            a.stat_part[((long)b * (a.Cout / a.stat_cg) + g) * S + (long)tile * gq + q] = ssum;
+        for (int o = 8; o >= 1; o >>= 1) {
+            ssum += __shfl_xor(ssum, o, 16);
+            if (smode == 1) ssq += __shfl_xor(ssq, o, 16);
+        }
+        if (sg >= 8) {
+            ssum += __shfl_xor(ssum, 16, 64);
+            if (smode == 1) ssq += __shfl_xor(ssq, 16, 64);
+        }
+        if (sg == 16) {
+            ssum += __shfl_xor(ssum, 32, 64);
+            if (smode == 1) ssq += __shfl_xor(ssq, 32, 64);
+        }
+        if (l15 == 0 && ((4 * lk) & (sg - 1)) == 0) {
+            const int spg = a.stat_cg / sg, cu = (cot0 + 4 * lk) / sg;      // slots per (tile, group); this slot's channel run
+            const int g = cu / spg, q = cu - g * spg;
+            const long S = (long)ntiles * spg;
+            const long idx = ((long)b * (a.Cout / a.stat_cg) + g) * S + (long)tile * spg + q;
+            if (smode == 1) {
+                a.stat_part[2 * idx] = ssum;
+                a.stat_part[2 * idx + 1] = ssq;
+            } else
+                a.stat_part[idx] = ssum;
         }
     }
 }
@@ -891,7 +918,8 @@ extern "C" int babe_conv2d_wino85_supported(const babe_conv_args* ap) {
 extern "C" int babe_conv2d_wino85_stat_slots(const babe_conv_args* ap) {
     if (!ap || ap->stat_cg < 4 || ap->stat_cg % 4 != 0 || ap->dil < 1 || ap->F < 1 || ap->T < 1) return 0;
     const babe_conv_args& a = *ap;
-    return cdiv(a.T, 64) * a.dil * cdiv(cdiv(a.F, a.dil), 4) * (a.stat_cg / 4);
+    const int sg = a.stat_cg % 16 == 0 ? 16 : (a.stat_cg % 8 == 0 ? 8 : 4);
+    return cdiv(a.T, 64) * a.dil * cdiv(cdiv(a.F, a.dil), 4) * (a.stat_cg / sg);
 }
 
 /* fraction of the row-quad x time slots of a launch that hold real outputs */
@@ -924,9 +952,10 @@ extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino8
     BABE_CHECK_ARG(babe_conv2d_wino85_supported(ap), "conv2d_wino85: unsupported problem");
     const babe_conv_args& a = *ap;
     if (a.stat_mode) {
-        BABE_CHECK_ARG(a.stat_mode == 2 && a.stat_part && a.stat_x && a.stat_scale && a.stat_cg >= 4 && a.stat_cg % 4 == 0 &&
-                           a.Cout % a.stat_cg == 0 && ((uintptr_t)a.stat_x & 15) == 0 && a.res == nullptr,
+        BABE_CHECK_ARG((a.stat_mode == 1 || a.stat_mode == 2) && a.stat_part && a.stat_cg >= 4 && a.stat_cg % 4 == 0 && a.Cout % a.stat_cg == 0,
                        "conv2d_wino85: fused reduction: mode %d, group size %d (Cout %d)", a.stat_mode, a.stat_cg, a.Cout);
+        BABE_CHECK_ARG(a.stat_mode == 1 || (a.stat_x && a.stat_scale && ((uintptr_t)a.stat_x & 15) == 0 && a.res == nullptr),
+                       "conv2d_wino85: fused reduction, mode 2: stat_x (16-byte aligned) and stat_scale are needed, res is not taken");
     }
     Wino85Geom g;
     g.CinP = a.Cin;

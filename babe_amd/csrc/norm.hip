@@ -202,13 +202,27 @@ __global__ __launch_bounds__(256) void scale_gelu_fin_kernel(const float* __rest
                                                              float* __restrict__ a, int C, int G, long hw, long n, int S,
                                                              float eps) {
     __shared__ float sc_sh;
+    __shared__ double red_sh[512];
     const int c = blockIdx.y, b = blockIdx.z;
     const int cg = C / G, g = c / cg;
-    if (threadIdx.x < 32) {
+    // All 256 threads fetch the S partial sums (a conv epilogue's fused sums come in hundreds to thousands of slots); thread q < 32 then adds the sums of threads q, q + 32, ...
+    // in that order - for S <= 256 exactly the additions, in the order, of the 32-thread loop this replaces (and of gn_finalize).
+    {
         double t0 = 0, t1 = 0;
-        for (int q = threadIdx.x; q < S; q += 32) {
+        for (int q = threadIdx.x; q < S; q += 256) {
             t0 += part[((long)(b * G + g) * S + q) * 2];
             t1 += part[((long)(b * G + g) * S + q) * 2 + 1];
+        }
+        red_sh[threadIdx.x * 2] = t0;
+        red_sh[threadIdx.x * 2 + 1] = t1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t0 = 0, t1 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            t0 += red_sh[(threadIdx.x + 32 * j) * 2];
+            t1 += red_sh[(threadIdx.x + 32 * j) * 2 + 1];
         }
 #pragma unroll
         for (int o = 16; o >= 1; o >>= 1) {

@@ -129,9 +129,11 @@ struct Ctx {
     void ck(int e) { if (e && !err) err = e; }
 
     // ---- ops (each = one extern "C" call of this library; nothing runs in a dry pass or after an error)
-    void conv(const View& x, const babe_packed_conv& pc, const View& out, int dil, bool transpose, const View* x2, const View* res,
-              const float* in_scale, const float* oscale, float alpha, float rbeta) {
-        if (dry() || err) return;
+    // stat_cg / stat_part: also form the GroupNorm sums of the output in the conv's epilogue (babe_conv_args::stat_mode 1); returns
+    // true if the kernel that ran the conv produced them (only the F(4,5) kernels do)
+    bool conv(const View& x, const babe_packed_conv& pc, const View& out, int dil, bool transpose, const View* x2, const View* res,
+              const float* in_scale, const float* oscale, float alpha, float rbeta, int stat_cg = 0, double* stat_part = nullptr) {
+        if (dry() || err) return false;
         babe_conv_args a;
         memset(&a, 0, sizeof a);
         a.in = x.p; a.in_bs = x.bs; a.in_cs = x.cs;
@@ -140,7 +142,16 @@ struct Ctx {
         if (res) { a.res = res->p; a.res_bs = res->bs; a.res_cs = res->cs; }
         a.in_scale = in_scale; a.oscale = oscale; a.alpha = alpha; a.rbeta = rbeta;
         a.B = B(); a.F = x.F; a.T = x.T; a.dil = dil;
+        if (stat_part) { a.stat_mode = 1; a.stat_cg = stat_cg; a.stat_part = stat_part; }
         ck(babe_conv2d_auto(&a, &pc, transpose ? 1 : 0, st));
+        return a.stat_mode == 1;
+    }
+    // slots per group of the fused reduction for a [C][F][T] output at this dilation (babe_conv2d_wino85_stat_slots)
+    static int stat_slots(int cg, int F, int T, int dil) {
+        babe_conv_args a;
+        memset(&a, 0, sizeof a);
+        a.stat_cg = cg; a.F = F; a.T = T; a.dil = dil;
+        return babe_conv2d_wino85_stat_slots(&a);
     }
     void axpby(const View& x, const View& out, float alpha = 1.f, float beta = 0.f) {
         if (dry() || err) return;
@@ -185,6 +196,8 @@ struct Ctx {
             z = buf(N, Fq, T);
             axpby(x, z);
         }
+        double* zpart = nullptr;                 // GroupNorm sums of z formed by the conv that wrote it (zS slots per group; 0: none)
+        int zS = 0;
         for (int d = 0; d < blk.nd; ++d) {
             // gate = film[:, goff : goff + N] made contiguous ([B][N]: the conv's oscale / the VJP's in_scale)
             float* gate;
@@ -201,12 +214,23 @@ struct Ctx {
             float* stats = alloc((size_t)B() * G_GROUPS * 3);
             float* scale = alloc((size_t)B() * N);
             if (!dry() && !err) {
-                ck(babe_gn_partial(z.p, part, B(), G_GROUPS, n, Sp, st));
-                ck(babe_scale_gelu_fin(z.p, part, blk.gamma[d], film_at(blk.film_aff[d]), S->film_bs, stats, scale, a, B(), N, G_GROUPS,
-                                       (long)Fq * T, Sp, GN_EPS, st));
+                if (!zS) ck(babe_gn_partial(z.p, part, B(), G_GROUPS, n, Sp, st));
+                ck(babe_scale_gelu_fin(z.p, zS ? zpart : part, blk.gamma[d], film_at(blk.film_aff[d]), S->film_bs, stats, scale, a, B(), N,
+                                       G_GROUPS, (long)Fq * T, zS ? zS : Sp, GN_EPS, st));
             }
             View av = z; av.p = a; av.cs = (long)Fq * T; av.bs = (long)N * Fq * T;
-            conv(av, blk.H[d], znew, blk.k53 ? (1 << d) : 1, false, nullptr, &z, nullptr, gate, RS2, RS2);
+            // the next layer's GroupNorm reads znew: its sums come out of this conv's epilogue when the F(4,5) kernel runs it
+            // (unet_engine.py: ops.conv2d(..., fwd_stat=))
+            const int dil = blk.k53 ? (1 << d) : 1, cg = N / G_GROUPS;
+            double* npart = nullptr;
+            int nS = 0;
+            if (fuse_gn_fwd() && d + 1 < blk.nd && blk.k53 && cg % 4 == 0) {
+                nS = stat_slots(cg, Fq, T, dil);
+                npart = reinterpret_cast<double*>(alloc((size_t)B() * G_GROUPS * nS * 2 * 2));
+            }
+            const bool made = conv(av, blk.H[d], znew, dil, false, nullptr, &z, nullptr, gate, RS2, RS2, cg, npart);
+            zS = made ? nS : 0;
+            zpart = npart;
             saved[d] = Saved{z, stats, scale, gate};
             z = znew;
         }
@@ -224,7 +248,7 @@ struct Ctx {
     int conv_vjp(const View& src, const babe_unet_block& blk, int d, const View& da, const Saved& sv, double** part) {
         const View& z = sv.z;
         const int dil = blk.k53 ? (1 << d) : 1, cg = z.C / G_GROUPS;
-        const int Sf = ((z.T + 63) / 64) * dil * ((((z.F + dil - 1) / dil) + 3) / 4) * (cg / 4);
+        const int Sf = cg % 4 == 0 ? stat_slots(cg, z.F, z.T, dil) : 0;
         const long n = (long)cg * z.F * z.T;
         const int Sp = splits(n);
         *part = reinterpret_cast<double*>(alloc((size_t)B() * G_GROUPS * (Sf > Sp ? Sf : Sp) * 2));     // (floats: 2 per double)
@@ -240,6 +264,10 @@ struct Ctx {
         }
         ck(babe_conv2d_auto(&a, &blk.H[d], 1, st));
         return a.stat_mode == 2 ? Sf : 0;
+    }
+    static bool fuse_gn_fwd() {
+        static const bool on = [] { const char* e = getenv("BABE_FUSE_GN_FWD"); return !(e && atoi(e) == 0); }();   // (on by default: ops.py FUSE_GN_FWD)
+        return on;
     }
     static bool fuse_gn() {
         static const bool on = [] { const char* e = getenv("BABE_FUSE_GN"); return e && atoi(e) != 0; }();   // (off by default: ops.py FUSE_GN)

@@ -154,6 +154,7 @@ class UnetEngine:
         units = blk.nd > 0 and ops.units_ok(blk.H[0], N, N, T) and z.is_contiguous()
         if units:
             au = self.scratch_i16("au", B * ops.lib().babe_units_size(N, Fq, T) * 8)
+        zsum = None                                          # (part, S): GroupNorm sums of z formed by the conv that wrote it
         for d in range(blk.nd):
             aoff, goff = blk.film_off[d]
             gate = self._film(film, goff, N).contiguous()
@@ -163,10 +164,15 @@ class UnetEngine:
                 stats, scale = ops.gn_scale(z, blk.gamma[d], self._film(film, aoff, N))
                 ops.scale_gelu_units(z, scale, au)
                 ops.conv2d_units(au, blk.H[d], znew, N, args=ua)
+                zsum = None
             else:
                 a = self.scratch("a", B * N * Fq * T).view(B, N, Fq, T)
-                stats, scale = ops.gn_scale_gelu(z, blk.gamma[d], self._film(film, aoff, N), a)     # (finalize inside the GELU launch)
-                ops.conv2d(a, blk.H[d], znew, dil=blk.dil(d), res=z, oscale=gate, alpha=RS2, rbeta=RS2)
+                stats, scale = ops.gn_scale_gelu(z, blk.gamma[d], self._film(film, aoff, N), a, fused=zsum)  # (finalize inside the GELU launch)
+                # the next layer's GroupNorm reads znew: its sums come out of this conv's epilogue when the F(4,5) kernel runs it
+                zsum = ops.conv2d(a, blk.H[d], znew, dil=blk.dil(d), res=z, oscale=gate, alpha=RS2, rbeta=RS2,
+                                  fwd_stat=(N // 8) if d + 1 < blk.nd else None)
+                if d + 1 >= blk.nd:
+                    zsum = None
             saved.append((z, stats, scale, gate))
             z = znew
         if blk.proj_out is not None:

@@ -127,16 +127,21 @@ class PackedConv:
 # default - measured 0.5 % slower than the separate pass (profiles/r06_gn_fusion_experiment.txt: the GELU' arithmetic runs on the
 # multiply waves with nothing to overlap it); BABE_FUSE_GN=1 turns it on (tests/test_gpu_ops.py keeps it parity-checked)
 FUSE_GN = os.environ.get("BABE_FUSE_GN", "0") != "0"
+# The NEXT layer's GroupNorm sums (sum, sum of squares of the output) formed in the forward F(4,5) conv's epilogue instead of
+# babe_gn_partial's pass over the freshly written output: two double additions per output, no extra loads.  BABE_FUSE_GN_FWD=0: own pass.
+FUSE_GN_FWD = os.environ.get("BABE_FUSE_GN_FWD", "1") != "0"
 
 
 def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=None, oscale=None, alpha=1.0, rbeta=0.0,
-           force_nested=False, force_f45=False, vjp_stat=None):
+           force_nested=False, force_f45=False, vjp_stat=None, fwd_stat=None):
     """out = alpha*conv(x[,x2]; W)*oscale + rbeta*res   (transpose=True: input-VJP weights).
     force_nested: take the nested-Winograd F(2,5) x F(4,3) kernel whenever it CAN run the problem (tests), not only when it is
     preferred; force_f45: the same for the F(4,5) x F(4,3) kernel.
     vjp_stat=(z, scale, cg): if the launch takes the F(4,5) kernel, its epilogue also forms the partial sums of the GroupNorm /
     FiLM / GELU input-VJP for the gradient `out` it writes (z: the layer's saved input, dense like out; scale [B,C]; cg channels
-    per group) and (part, S) is RETURNED for gn_bwd(part=, S=); otherwise None is returned and gn_bwd runs its own pass."""
+    per group) and (part, S) is RETURNED for gn_bwd(part=, S=); otherwise None is returned and gn_bwd runs its own pass.
+    fwd_stat=cg: likewise the sums of the output itself - the next layer's GroupNorm partial sums - for gn_scale_gelu(fused=);
+    (part, S) or None is returned."""
     a = ConvArgs()
     B, C1, F, T = x.shape
     Cin = pc.Cout if transpose else pc.Cin
@@ -182,8 +187,14 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
             part = torch.empty(B * (Cout // cg) * S, device=x.device, dtype=torch.float64)
             a.stat_part = ptr(part)
             fused = (part, S)
+        elif fwd_stat is not None and FUSE_GN_FWD and out.is_contiguous():
+            a.stat_mode, a.stat_cg = 1, fwd_stat
+            S = lib().babe_conv2d_wino85_stat_slots(C.byref(a))
+            part = torch.empty(B * (Cout // fwd_stat) * S * 2, device=x.device, dtype=torch.float64)
+            a.stat_part = ptr(part)
+            fused = (part, S)
         check(lib().babe_conv2d_wino85(C.byref(a), ptr(pc.bwd_wino85 if transpose else pc.fwd_wino85), stream()), "conv2d_wino85")
-        return fused if vjp_stat is not None else out
+        return fused if (vjp_stat is not None or fwd_stat is not None) else out
     elif getattr(pc, "bwd_wino45" if transpose else "fwd_wino45", None) is not None and (lib().babe_conv2d_wino45_supported(C.byref(a)) if force_nested
                                                           else lib().babe_conv2d_wino45_preferred(C.byref(a))):
         check(lib().babe_conv2d_wino45(C.byref(a), ptr(pc.bwd_wino45 if transpose else pc.fwd_wino45), stream()), "conv2d_wino45")
@@ -193,7 +204,7 @@ def conv2d(x, pc, out, *, dil=1, transpose=False, x2=None, res=None, in_scale=No
         check(lib().babe_conv2d_wino(C.byref(a), ptr(pc.bwd_wino if transpose else pc.fwd_wino), stream()), "conv2d_wino")
     else:
         check(lib().babe_conv2d_nt(C.byref(a), pc.nt, stream()), "conv2d")
-    return None if vjp_stat is not None else out
+    return None if (vjp_stat is not None or fwd_stat is not None) else out
 
 
 def _splits(n, B, G):
@@ -245,9 +256,19 @@ def gn_scale(x, gamma, film, G=8, eps=1e-7):
 GELU_FIN = os.environ.get("BABE_GELU_FIN", "1") != "0"
 
 
-def gn_scale_gelu(x, gamma, film, out, G=8, eps=1e-7):
+def gn_scale_gelu(x, gamma, film, out, G=8, eps=1e-7, fused=None):
     """gn_scale + scale_gelu with the finalize folded into the GELU kernel's prologue: out = gelu(x * scale); returns
-    (stats [B,G,3], scale [B,C]) for the VJP.  Bit-identical to gn_scale followed by scale_gelu (BABE_GELU_FIN=0)."""
+    (stats [B,G,3], scale [B,C]) for the VJP.  Bit-identical to gn_scale followed by scale_gelu (BABE_GELU_FIN=0).
+    fused=(part, S): the partial sums of x already formed by the conv that wrote it (conv2d(fwd_stat=)): no pass over x for them."""
+    if fused is not None:
+        assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape and film.stride(1) == 1
+        B, Cc, F, T = x.shape
+        part, S = fused
+        stats = torch.empty(B, G, 3, device=x.device, dtype=torch.float32)
+        scale = torch.empty(B, Cc, device=x.device, dtype=torch.float32)
+        check(lib().babe_scale_gelu_fin(ptr(x), ptr(part), ptr(gamma), ptr(film), film.stride(0), ptr(stats), ptr(scale), ptr(out),
+                                        B, Cc, G, F * T, S, eps, stream()), "scale_gelu_fin")
+        return stats, scale
     if not GELU_FIN:
         stats, scale = gn_scale(x, gamma, film, G, eps)
         scale_gelu(x, scale, out)

@@ -475,7 +475,7 @@ def main():
                           "of those steps" % (n_prof, max(1, min(sampler.LANES, nseg * C_))),
                 "overlap_factor": round(sum_all_ms * 1e-3 / wall_prof, 4),
                 "conv_time_share_of_kernel_time": round(sum_conv_ms / sum_all_ms, 4),
-                "conv_dispatch_counts_timed_region": {k: counts[k] for k in CONV_SLOTS + ["dft_stage"]},
+                "conv_dispatch_counts_timed_region": {k: counts[k] for k in CONV_SLOTS + ["dft_stage", "gn_stats", "scale_gelu", "gn_bwd_partial", "gn_bwd_apply"]},
                 "all_conv_kernels": slot_table(timed, CONV_SLOTS),
             }
             if serial is not None and serial[dom]["launches"]:

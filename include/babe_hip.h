@@ -35,6 +35,9 @@ typedef struct {
     int B, Cin, Cout, F, T, KH, KW, dil;
     /* Optional reduction fused into the EPILOGUE of the F(4,5) x F(4,3) kernels (babe_conv2d_wino85; every other kernel ignores
      * these fields - zero them): the sums a GroupNorm pass would otherwise re-read the freshly written output for (round 6).
+     *   stat_mode 1: stat_part[((b*G + g)*S + slot)*2 + {0,1}] = sum, sum of squares of the slot's outputs (the values stored in
+     *                out) - the partial sums of the NEXT layer's GroupNorm, in the layout babe_scale_gelu_fin / babe_gn_finalize read
+     *                with that S (what babe_gn_partial would re-read out for).
      *   stat_mode 2: stat_part[(b*G + g)*S + slot] = sum over the slot's outputs y of y * u * gelu'(u), u = stat_scale[b][c] *
      *                stat_x[b][c][f][t] - the S_g partial sums of the GroupNorm / FiLM / GELU input-VJP (babe_gn_bwd_partial) for
      *                the transposed conv that writes da; stat_x: dense [B][Cout][F][T] (the layer's saved input), stat_scale [B][Cout].
@@ -43,7 +46,8 @@ typedef struct {
     int stat_mode, stat_cg;
     const float* stat_x; const float* stat_scale; double* stat_part;
 } babe_conv_args;
-/* slots per GroupNorm group the fused reduction writes: (row-quad x time tiles of the launch) * stat_cg / 4 */
+/* slots per GroupNorm group the fused reduction writes: (row-quad x time tiles of one batch element) * stat_cg / sg, sg = the largest
+ * of 16, 8, 4 that divides stat_cg */
 int babe_conv2d_wino85_stat_slots(const babe_conv_args* a);
 int babe_conv2d(const babe_conv_args* a, void* stream);
 /* w: [Cout][Cin][KH][KW] (reference layout) -> packed; transpose_flip=1 builds the bwd-data weights

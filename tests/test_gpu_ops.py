@@ -1,4 +1,5 @@
 """HIP ops (through the C-ABI) vs the CPU oracle on seeded inputs.  Needs a MI355X."""
+import ctypes as C
 import math
 
 import pytest
@@ -826,6 +827,55 @@ def test_conv2d_f45_dispatch_rule_and_tile_order(ops):
     dispatch_counts(reset=True)
     ops.conv2d(xa, pc, out, dil=4, x2=xb)
     assert dispatch_counts()["conv53_wino85"] == 0
+
+
+def test_f45_epilogue_forms_the_next_groupnorm_sums(ops, monkeypatch):
+    """Round 6: the forward (5,3) conv that writes a layer's output also forms, in its epilogue, the sum and sum of squares per group
+    that the NEXT layer's GroupNorm needs (babe_conv_args::stat_mode 1) - for the 128- (12- and 8-wave), 96-, 64- and 256-channel
+    forms, ragged time tiles and partly filled row quads included: output bit-identical with and without the reduction, group totals
+    against float64 sums of the output, and gn_scale_gelu on the fused sums against its own pass (statistics to float rounding,
+    the activation to 1e-5)."""
+    from babe_amd._lib import dispatch_counts, lib
+    monkeypatch.setattr(ops, "FUSE_GN_FWD", True)
+    RS2 = 1.0 / math.sqrt(2.0)
+    for Cc, Fq, T, dil, waves in ((128, 48, 128, 2, 12), (128, 48, 128, 2, 8), (96, 40, 192, 1, 12), (64, 36, 100, 3, 12), (256, 28, 64, 4, 12),
+                                  (128, 5, 64, 1, 12)):
+        assert lib().babe_conv2d_wino85_set_waves(waves) == 0
+        g = torch.Generator().manual_seed(Cc + Fq + T + 1)
+        B = 2
+        a_in = torch.randn(B, Cc, Fq, T, generator=g).cuda()
+        z = torch.randn(B, Cc, Fq, T, generator=g).cuda()
+        w = (torch.randn(Cc, Cc, 5, 3, generator=g) / math.sqrt(Cc * 15)).cuda()
+        gate = torch.randn(B, Cc, generator=g).cuda()
+        gamma = (0.5 + torch.rand(Cc, generator=g)).cuda()
+        film = (0.1 * torch.randn(B, Cc, generator=g)).cuda()
+        pc = ops.PackedConv(w)
+        o0, o1 = torch.empty_like(z), torch.empty_like(z)
+        dispatch_counts(reset=True)
+        ops.conv2d(a_in, pc, o0, dil=dil, res=z, oscale=gate, alpha=RS2, rbeta=RS2, force_f45=True)
+        fs = ops.conv2d(a_in, pc, o1, dil=dil, res=z, oscale=gate, alpha=RS2, rbeta=RS2, force_f45=True, fwd_stat=Cc // 8)
+        assert dispatch_counts()["conv53_wino85"] == 2 and fs is not None
+        assert torch.equal(o0, o1)
+        part, S = fs
+        assert S == lib().babe_conv2d_wino85_stat_slots(C.byref(_stat_args(Cc // 8, Fq, T, dil)))
+        got = part.view(B, 8, S, 2).sum(2)
+        x64 = o0.double().view(B, 8, -1)
+        want = torch.stack([x64.sum(-1), (x64 * x64).sum(-1)], -1)
+        err = float(((got - want).abs() / torch.stack([x64.abs().sum(-1), (x64 * x64).sum(-1)], -1)).max())
+        assert err < 1e-12, (Cc, waves, err)
+        act0, act1 = torch.empty_like(z), torch.empty_like(z)
+        st0, sc0 = ops.gn_scale_gelu(o0, gamma, film, act0)
+        st1, sc1 = ops.gn_scale_gelu(o0, gamma, film, act1, fused=fs)
+        assert float((st0 - st1).abs().max()) < 1e-6 and float(((sc0 - sc1) / sc0).abs().max()) < 1e-6
+        assert float((act0 - act1).abs().max()) < 1e-5
+    assert lib().babe_conv2d_wino85_set_waves(12) == 0
+
+
+def _stat_args(cg, F, T, dil):
+    from babe_amd._lib import ConvArgs
+    a = ConvArgs()
+    a.stat_cg, a.F, a.T, a.dil = cg, F, T, dil
+    return a
 
 
 def test_f45_epilogue_forms_the_groupnorm_vjp_partial_sums(ops, monkeypatch):
