@@ -90,6 +90,37 @@ def test_c_engine_equals_python_engine_full_width(monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_groupnorm_sums_from_the_conv_epilogue_leave_the_network_unchanged(monkeypatch):
+    """Round 6: with BABE_FUSE_GN_FWD (the default) the forward (5,3) convs on the F(4,5) kernel hand the next layer's GroupNorm its
+    sums (babe_conv_args::stat_mode 1) instead of a pass of babe_gn_partial over the tensor: fewer statistics launches, and the
+    network's outputs and input-VJP equal to the own-pass form to float rounding of the statistics (the sums are the same numbers
+    added in another order, in double)."""
+    from babe_amd import ops
+    from babe_amd._lib import dispatch_counts
+    from babe_amd.networks import unet_engine as ue
+    from babe_amd.networks.cqtdiff_plus import init_state_dict
+    Ns, nd = [64, 96, 96, 128, 128, 256, 256], [2, 3, 4, 5, 6, 7, 7]
+    sd = {k: v.cuda() for k, v in init_state_dict(Ns, nd, seed=3, gate_scale=1.0).items()}
+    gen = torch.Generator().manual_seed(12)
+    Ts = [16 * 2 ** j for j in range(7)]
+    C_list = [torch.randn(1, 2, 64, T, generator=gen).cuda() for T in Ts]
+    gouts = [torch.randn(c.shape, generator=gen).cuda() for c in C_list]
+    cn = torch.tensor([[-0.7]]).cuda()
+    monkeypatch.setattr(ue, "USE_C", False)
+    res, launches = [], []
+    for fuse in (False, True):
+        monkeypatch.setattr(ops, "FUSE_GN_FWD", fuse)
+        eng = ue.UnetEngine(sd, Ns, nd)
+        film = eng.embed(cn)
+        dispatch_counts(reset=True)
+        o, g = _run(eng, C_list, film, gouts)
+        launches.append(dispatch_counts()["gn_stats"])
+        res.append([t.clone() for t in o + g])
+    assert launches[1] < launches[0], launches
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), float((a - b).abs().max() / a.abs().max())
+
+
 def test_workspace_too_small_fails_loudly():
     from babe_amd._lib import lib
     from babe_amd.networks import unet_engine as ue
