@@ -45,6 +45,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef W85_RD
 #define W85_RD 12      // weight register ring: groups in flight (a multiple of 3 that divides 24)
 #endif
+#ifndef W85_TFIRST
+#define W85_TFIRST 1    // specialised-wave kernels: the transform waves are the OLDEST waves of the workgroup (0: the youngest, round 5 - 6a)
+#endif
+#ifndef W85_TPRIO
+#define W85_TPRIO 0
+#endif
+// timing probe (ablation bit 16384, tools/f45_barrier_probe.py): cycles a wave spends at the per-super-slab barrier and in total,
+// written by lane 0 of the first multiplying and the first transform wave to stat_part[tile * 4 ..] (stat_mode 99)
+#define W85_PROBE (W85_ABL & 16384)
+#if W85_PROBE
+#define W85_BARRIER(acc_)                                              \
+    {                                                                  \
+        const unsigned long long tb_ = __builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_s_barrier();                                  \
+        acc_ += __builtin_amdgcn_s_memtime() - tb_;                    \
+    }
+#else
+#define W85_BARRIER(acc_) __builtin_amdgcn_s_barrier();
+#endif
 #ifndef W85_ABL
 #define W85_ABL 0      // timing ablations only (tools/f45_ablate.py): 1 no transform arithmetic, 2 no row loads, 4 no weight loads,
 #endif                 // 8 no X reads, 16 no MFMA, 32 rows loaded by waves 0-3 only, 64 / 128 row loads that always hit L2 / L1, 512 no epilogue, 1024 no pass carry - results are wrong
@@ -253,7 +272,7 @@ __device__ __forceinline__ void w85_epilogue(const babe_conv_args& a, const f32x
             for (int kk = 0; kk < 4; ++kk) ld[row + 2][kk] = *reinterpret_cast<const f32x4*>(lsrc + ((co0 + kk) * lcs + spr[row + 2]));
         }
     }
-    if (smode) {
+    if (smode == 1 || smode == 2) {
         // The 16 lanes of a row (same lk) hold the same channel quad, the wave 16 consecutive channels: a slot = the largest run of
         // channels (4, 8 or 16) that divides the group size, summed in the wave in a fixed order and written exactly once.
         const int sg = (a.stat_cg & 15) == 0 ? 16 : ((a.stat_cg & 7) == 0 ? 8 : 4);
@@ -591,7 +610,13 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The hardware issues oldest wave first: with the transform waves as the workgroup's LAST waves their instructions got what the
+    // two multiplying waves of their SIMD left over, most of a super-slab's transform ran alone after the MFMAs, and the multiplying
+    // waves stood at the barrier for 53 % (first wave of a SIMD) / 20 % (second) of the main loop (s_memtime probe, ablation bit 16384,
+    // profiles/r06_f45_barrier_probe.txt).  The FIRST TW hardware waves transform; `wave` stays the logical index the rest of the
+    // kernel uses: 0 .. NW-1 multiply, NW .. NWV-1 transform.
+    const int wave_hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = W85_TFIRST ? (wave_hw < NWV - NW ? NW + wave_hw : wave_hw - (NWV - NW)) : wave_hw;
     const int l15 = lane & 15, lk = lane >> 4;
     const int b = blockIdx.z;
     int bx = blockIdx.x, by = blockIdx.y;
@@ -612,6 +637,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
 
     if (wave >= NW) {
         // ================= transform waves =================
+#if W85_TPRIO            // (experiment: the transform waves above the multiplying waves of their SIMD)
+        __builtin_amdgcn_s_setprio(W85_TPRIO);
+#endif
+        unsigned long long pb_wait = 0;
+        const unsigned long long pb_t0 = W85_PROBE ? __builtin_amdgcn_s_memtime() : 0ull;
         const float* p1 = a.in + (long)b * a.in_bs;
         const int cs1 = (int)a.in_cs;
         const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p1, 0, a.Cin * cs1 * 4, 0x00020000);
@@ -661,7 +691,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
         };
         // register set `st` (rows of a pass-`ps` super-slab) -> X buffer `buf`: both phase pairs of the pass for this thread's
         // (ci, unit) pairs; the arithmetic of conv_wino85_kernel's store_act, term for term
+        unsigned long long pb_vm = 0;                      // (probe: time waiting for the rows of the set about to be transformed)
         auto transform = [&](int st, int ps, f32x4* buf) __attribute__((always_inline)) {
+#if W85_PROBE
+            {
+                const unsigned long long tv_ = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // (at most 9 loads per channel quad are younger than this set's)
+                pb_vm += __builtin_amdgcn_s_memtime() - tv_;
+            }
+#endif
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 float xh[8];
@@ -705,7 +743,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
         transform(0, pT, Xb);                              // super-slab 0 -> X[0]
         advance(pT, cT);
         asm volatile("s_waitcnt lgkmcnt(0)");
-        __builtin_amdgcn_s_barrier();
+        W85_BARRIER(pb_wait)
         for (int S = 0; S < NS; S += 2) {
             // iteration S (even): set 0 is free (slab S was transformed last time): rows of slab S + 2; transform slab S + 1 (set 1)
             issue(0, pL, cL);
@@ -713,20 +751,27 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
             transform(1, pT, Xb + XSZ);
             advance(pT, cT);
             asm volatile("s_waitcnt lgkmcnt(0)");
-            __builtin_amdgcn_s_barrier();
+            W85_BARRIER(pb_wait)
             // iteration S + 1: rows of slab S + 3 into set 1; transform slab S + 2 (set 0) -> X[0]
             issue(1, pL, cL);
             advance(pL, cL);
             transform(0, pT, Xb);
             advance(pT, cT);
             asm volatile("s_waitcnt lgkmcnt(0)");
-            __builtin_amdgcn_s_barrier();
+            W85_BARRIER(pb_wait)
+        }
+        if (W85_PROBE && a.stat_mode == 99 && wave == NW && lane == 0) {
+            double* dbg = a.stat_part + 4 * ((long)b * g.total + (g.xcd ? blockIdx.x : blockIdx.x + gridDim.x * blockIdx.y));
+            dbg[2] = (double)pb_wait + 1e-9 * (double)pb_vm;     // (the row wait rides in the fraction: 1e-9 x ticks)
+            dbg[3] = (double)(__builtin_amdgcn_s_memtime() - pb_t0);
         }
         return;
     }
 
     // ================= multiplying waves =================
     // (a static s_setprio 1 / 3 for these waves over the transform wave of their SIMD: no effect, profiles/r06_12wave_ab.txt)
+    unsigned long long pb_wait = 0;
+    const unsigned long long pb_t0 = W85_PROBE ? __builtin_amdgcn_s_memtime() : 0ull;
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, 4 * g.CinP * g.CoutP * 48, 0x00020000);
     const int NT = g.CoutP >> 4;
     const int wstep = NT * 3072;
@@ -752,7 +797,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
         for (int p = 0; p < 12; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bv[2];
     bv[0] = bv[1] = f32x4{1.f, 2.f, 3.f, 4.f};
-    __builtin_amdgcn_s_barrier();                          // X[0] is complete
+    W85_BARRIER(pb_wait)                          // X[0] is complete
     Y_FENCE
 #if W85_ABL & 8
 #define Z_READ(c, Xp, hs, pg) asm volatile("" : "+v"(bv[c]));
@@ -788,7 +833,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
         Z_G(12) Z_G(13) Z_G(14) Z_G(15) Z_G(16) Z_G(17) Z_G(18) Z_G(19) Z_G(20) Z_G(21) Z_G(22)
         // G23: its operands are in registers; barrier (X[(S + 1) & 1] complete, nobody reads X[S & 1] any more)
         asm volatile("s_waitcnt lgkmcnt(0)");
-        __builtin_amdgcn_s_barrier();
+        W85_BARRIER(pb_wait)
         Y_FENCE
         Z_READ(0, Xw, 0, 0)
         Y_FENCE
@@ -808,6 +853,16 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
 #undef Z_READ
 #undef Z_WLOAD
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+    if (W85_PROBE && a.stat_mode == 99 && lane == 0) {
+        double* dbg = a.stat_part + 4 * ((long)b * g.total + (g.xcd ? blockIdx.x : blockIdx.x + gridDim.x * blockIdx.y));
+        if (wave == 0) {
+            dbg[0] = (double)pb_wait;
+            dbg[1] = (double)(__builtin_amdgcn_s_memtime() - pb_t0);
+        }
+        // every multiplying wave's barrier share, behind the per-tile records (tools/f45_barrier_probe.py: offset 4 * (tiles + 64))
+        a.stat_part[4 * ((long)g.total + 64) + 8 * (g.xcd ? blockIdx.x : blockIdx.x + gridDim.x * blockIdx.y) + wave] =
+            (double)pb_wait / (double)(__builtin_amdgcn_s_memtime() - pb_t0);
+    }
 
     w85_epilogue(a, acc, b, co0 + wave * 16, fa, t0, lk, l15, g.xcd ? bx : Q * g.tiles_t + tile_t, g.tiles_t * nQ);
 #endif
@@ -952,9 +1007,9 @@ extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino8
     BABE_CHECK_ARG(babe_conv2d_wino85_supported(ap), "conv2d_wino85: unsupported problem");
     const babe_conv_args& a = *ap;
     if (a.stat_mode) {
-        BABE_CHECK_ARG((a.stat_mode == 1 || a.stat_mode == 2) && a.stat_part && a.stat_cg >= 4 && a.stat_cg % 4 == 0 && a.Cout % a.stat_cg == 0,
+        BABE_CHECK_ARG((a.stat_mode == 1 || a.stat_mode == 2 || (W85_PROBE && a.stat_mode == 99)) && a.stat_part && a.stat_cg >= 4 && a.stat_cg % 4 == 0 && a.Cout % a.stat_cg == 0,
                        "conv2d_wino85: fused reduction: mode %d, group size %d (Cout %d)", a.stat_mode, a.stat_cg, a.Cout);
-        BABE_CHECK_ARG(a.stat_mode == 1 || (a.stat_x && a.stat_scale && ((uintptr_t)a.stat_x & 15) == 0 && a.res == nullptr),
+        BABE_CHECK_ARG(a.stat_mode != 2 || (a.stat_x && a.stat_scale && ((uintptr_t)a.stat_x & 15) == 0 && a.res == nullptr),
                        "conv2d_wino85: fused reduction, mode 2: stat_x (16-byte aligned) and stat_scale are needed, res is not taken");
     }
     Wino85Geom g;
