@@ -48,12 +48,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef W85_TFIRST
 #define W85_TFIRST 1    // specialised-wave kernels: the transform waves are the OLDEST waves of the workgroup (0: the youngest, round 5 - 6a)
 #endif
+// W85_FLAGS (round 6, the default): no barrier inside the main loop of the specialised-wave kernels.  THREE X buffers; every transform
+// wave publishes the number of super-slabs it has finished (prog[t]), every multiplying wave the number it has consumed (cons[w]), in
+// LDS words of their own (no atomics); a consumer polls the words of the other side (one ds_read_b128 per side and super-slab when
+// nothing is late).  A wave then waits only for data it needs, not for the slowest wave of the workgroup: the first multiplying wave
+// of a SIMD, which the oldest-first issue order lets through a super-slab in half its time, goes on into the next one and fills the
+// matrix pipe while its partner waits for weights.  Same arithmetic in the same order: bit-identical to the barrier form
+// (-DW85_FLAGS=0, which the s_memtime probe needs).  +1.0 ... 1.25 % on the job, profiles/r06_f45_flags_ab.txt.
+#ifndef W85_FLAGS
+#define W85_FLAGS 1
+#endif
+#ifndef W85_NXB
+#define W85_NXB 3       // X buffers of the flag-synchronised form (3 or 4)
+#endif
+#ifndef W85_SLEEP
+#define W85_SLEEP 1     // s_sleep argument inside its polling loops (0: none)
+#endif
 #ifndef W85_TPRIO
 #define W85_TPRIO 0
 #endif
 // timing probe (ablation bit 16384, tools/f45_barrier_probe.py): cycles a wave spends at the per-super-slab barrier and in total,
 // written by lane 0 of the first multiplying and the first transform wave to stat_part[tile * 4 ..] (stat_mode 99)
 #define W85_PROBE (W85_ABL & 16384)
+#if W85_PROBE && W85_FLAGS
+#error "the barrier probe instruments the barrier form: build with -DW85_FLAGS=0"
+#endif
 #if W85_PROBE
 #define W85_BARRIER(acc_)                                              \
     {                                                                  \
@@ -634,6 +653,24 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
     const int cls = Q / g.nquads;
     const int fa = Q < a.dil * g.nquads ? cls + 4 * (Q - cls * g.nquads) * a.dil : a.F + 8 * a.dil;
     const int NS = 2 * (g.CinP / KS);                   // super-slabs (even)
+#if W85_FLAGS
+    // flags behind X[W85_NXB]: prog[0..3] (transform waves; unused words stay at "infinity"), cons[0..7] (multiplying waves)
+    unsigned* const flg = reinterpret_cast<unsigned*>(Xb + W85_NXB * XSZ);
+    const unsigned flg_a = (unsigned)(unsigned long long)flg;     // LDS byte address of the flags (low word of the flat address)
+    if (tid < 12) flg[tid] = (tid < 4 ? tid < TW : tid - 4 < NW) ? 0u : 0x7fffffffu;
+    __syncthreads();
+    // min over four flag words at byte address `ad`
+    auto flag_min4 = [&](unsigned ad) __attribute__((always_inline)) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ad) : "memory");
+        const unsigned m01 = v[0] < v[1] ? v[0] : v[1], m23 = v[2] < v[3] ? v[2] : v[3];
+        return __builtin_amdgcn_readfirstlane(m01 < m23 ? m01 : m23);
+    };
+    auto flag_set = [&](unsigned ad, unsigned val) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(ad), "v"(val) : "memory");
+    };
+#endif
 
     if (wave >= NW) {
         // ================= transform waves =================
@@ -736,6 +773,35 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
         };
         // super-slab s lives in register set s & 1; (pT, cT) = the slab transformed next, (pL, cL) = the slab loaded next
         int pT = 0, cT = 0, pL = 0, cL = 0;
+#if W85_FLAGS
+        issue(0, pL, cL);
+        advance(pL, cL);
+        issue(1, pL, cL);
+        advance(pL, cL);
+        int kb = 0;                                        // k mod NXB: the X buffer of slab k
+        const unsigned my_prog = flg_a + (unsigned)(wave - NW) * 4;
+        auto slab = [&](int st, int k) __attribute__((always_inline)) {
+            // buffer k mod NXB last held slab k - NXB: every multiplying wave must have consumed it (cons >= k - NXB + 1)
+            if (k >= W85_NXB) {
+                while (true) {
+                    const unsigned c0 = flag_min4(flg_a + 16), c1 = flag_min4(flg_a + 32);
+                    if ((int)(c0 < c1 ? c0 : c1) >= k - W85_NXB + 1) break;
+                    if (W85_SLEEP) __builtin_amdgcn_s_sleep(W85_SLEEP);
+                }
+            }
+            transform(st, pT, Xb + kb * XSZ);
+            advance(pT, cT);
+            flag_set(my_prog, (unsigned)(k + 1));          // (behind this wave's LDS writes: s_waitcnt lgkmcnt(0) first)
+            issue(st, pL, cL);                             // the set just transformed is free: rows of slab k + 2 (clamped at the end)
+            advance(pL, cL);
+            kb = kb == W85_NXB - 1 ? 0 : kb + 1;
+        };
+        for (int S = 0; S < NS; S += 2) {
+            slab(0, S);
+            slab(1, S + 1);
+        }
+        return;
+#endif
         issue(0, pL, cL);
         advance(pL, cL);
         issue(1, pL, cL);
@@ -797,7 +863,17 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
         for (int p = 0; p < 12; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bv[2];
     bv[0] = bv[1] = f32x4{1.f, 2.f, 3.f, 4.f};
+#if W85_FLAGS
+    const unsigned my_cons = flg_a + 16 + (unsigned)wave * 4;
+    auto wait_prog = [&](int need) __attribute__((always_inline)) {
+        while ((int)flag_min4(flg_a) < need)
+            if (W85_SLEEP) __builtin_amdgcn_s_sleep(W85_SLEEP);
+    };
+    wait_prog(1);                                          // X[0] is complete
+    int kb = 0;
+#else
     W85_BARRIER(pb_wait)                          // X[0] is complete
+#endif
     Y_FENCE
 #if W85_ABL & 8
 #define Z_READ(c, Xp, hs, pg) asm volatile("" : "+v"(bv[c]));
@@ -827,13 +903,25 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
     Z_READ(0, Xb, 0, 0)
     int cM = 0, pM = 0;
     for (int S = 0; S < NS; ++S) {
+#if W85_FLAGS
+        const int kbn = kb == W85_NXB - 1 ? 0 : kb + 1;
+        const f32x4* Xs = Xb + kb * XSZ;
+        const f32x4* Xw = Xb + kbn * XSZ;
+        kb = kbn;
+#else
         const f32x4* Xs = Xb + (S & 1) * XSZ;
         const f32x4* Xw = Xb + ((S + 1) & 1) * XSZ;
+#endif
         Z_G(0) Z_G(1) Z_G(2) Z_G(3) Z_G(4) Z_G(5) Z_G(6) Z_G(7) Z_G(8) Z_G(9) Z_G(10) Z_G(11)
         Z_G(12) Z_G(13) Z_G(14) Z_G(15) Z_G(16) Z_G(17) Z_G(18) Z_G(19) Z_G(20) Z_G(21) Z_G(22)
         // G23: its operands are in registers; barrier (X[(S + 1) & 1] complete, nobody reads X[S & 1] any more)
+#if W85_FLAGS
+        flag_set(my_cons, (unsigned)(S + 1));              // (behind this wave's reads of slab S: s_waitcnt lgkmcnt(0) first)
+        if (S + 1 < NS) wait_prog(S + 2);                  // slab S + 1 is complete
+#else
         asm volatile("s_waitcnt lgkmcnt(0)");
         W85_BARRIER(pb_wait)
+#endif
         Y_FENCE
         Z_READ(0, Xw, 0, 0)
         Y_FENCE
@@ -1019,7 +1107,21 @@ extern "C" int babe_conv2d_wino85(const babe_conv_args* ap, const float* w_wino8
     g.nquads = cdiv(cdiv(a.F, a.dil), 4);
     const double flops = babe_conv_flops(a);         // 48 multiplies per 16 outputs instead of 240: 0.2 of the direct count
     BabeProfScope prof(BABE_SLOT_CONV53_WINO85, babe_conv_bytes(a), flops, flops * 0.2, stream);
+#if W85_FLAGS
+    const size_t lds = (size_t)(W85_NXB * 16 * 16 * 6) * 16 + 64;             // X[NXB] + the progress words: 72 KB at 3
+    {
+        static std::atomic<unsigned long long> attr_done{0};
+        if (babe_lds_optin(attr_done, {reinterpret_cast<const void*>(&conv_wino85s_kernel<true, 8, 12>), reinterpret_cast<const void*>(&conv_wino85s_kernel<false, 8, 12>),
+                                       reinterpret_cast<const void*>(&conv_wino85s_kernel<true, 6>), reinterpret_cast<const void*>(&conv_wino85s_kernel<false, 6>),
+                                       reinterpret_cast<const void*>(&conv_wino85s_kernel<true, 4>), reinterpret_cast<const void*>(&conv_wino85s_kernel<false, 4>)},
+                           128 * 1024) != hipSuccess) {
+            babe_set_error("conv2d_wino85: cannot opt in to %zu bytes of LDS", lds);
+            return BABE_ERR_HIP;
+        }
+    }
+#else
     const size_t lds = (size_t)(2 * 16 * 16 * 6) * 16;                        // X[2]: 48 KB
+#endif
     static const int xcd_order = [] { const char* e = getenv("BABE_W85_XCD"); return e ? atoi(e) : 1; }();
     const int bn = a.Cout % 128 == 0 ? 128 : (a.Cout % 96 == 0 ? 96 : 64);
     g.xcd = xcd_order;

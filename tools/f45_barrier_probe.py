@@ -1,6 +1,7 @@
 """Where a workgroup of the 12-wave F(4,5) kernel waits: per-super-slab barrier time of the first multiplying wave and of the first
 transform wave against their total time (s_memtime, 100 MHz ticks on gfx950 - only ratios are used).  Needs a library with conv_wino85.hip
-built -DW85_ABL=16384 (tools/ab/variant_build.sh probe conv_wino85 -DW85_ABL=16384), selected with BABE_HIP_LIB."""
+built -DW85_ABL=16384 -DW85_FLAGS=0 (tools/ab/variant_build.sh probe conv_wino85 -DW85_ABL=16384 -DW85_FLAGS=0: the probe brackets the
+barrier of the barrier form; the default form since round 6 has none), selected with BABE_HIP_LIB."""
 import ctypes as C
 import math
 import os
