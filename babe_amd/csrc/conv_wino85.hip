@@ -635,7 +635,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv_wino85s_kernel(babe_conv_arg
     // profiles/r06_f45_barrier_probe.txt).  The FIRST TW hardware waves transform; `wave` stays the logical index the rest of the
     // kernel uses: 0 .. NW-1 multiply, NW .. NWV-1 transform.
     const int wave_hw = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = W85_TFIRST ? (wave_hw < NWV - NW ? NW + wave_hw : wave_hw - (NWV - NW)) : wave_hw;
+    // (W85_TFIRST == 2, experiment, 12-wave form only: the transform wave between the two multiplying waves of its SIMD in age)
+    const int wave = (W85_TFIRST == 2 && NWV == 12) ? (wave_hw < 4 ? wave_hw : (wave_hw < 8 ? NW + wave_hw - 4 : wave_hw - 4))
+                     : W85_TFIRST                   ? (wave_hw < NWV - NW ? NW + wave_hw : wave_hw - (NWV - NW))
+                                                    : wave_hw;
     const int l15 = lane & 15, lk = lane >> 4;
     const int b = blockIdx.z;
     int bx = blockIdx.x, by = blockIdx.y;
