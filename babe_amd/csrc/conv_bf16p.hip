@@ -354,36 +354,55 @@ __global__ __launch_bounds__(128 * G, (G == 4 ? 1 : 2)) void conv_bf16p_kernel(b
 #undef READ_S
 #undef MFMA_TAP
 
-    // ---- epilogue: out = alpha*acc*oscale[b,co] + rbeta*res; a lane's four tiles are four consecutive time steps
+    // ---- epilogue: out = alpha*acc*oscale[b,co] + rbeta*res; a lane's four tiles are four consecutive time steps.
+    // Round 6: through buffer descriptors like conv11p's - one per-lane byte offset per position (out of range when the position is
+    // padding) + a scalar term per channel, a channel beyond Cout lands beyond the descriptor - so that NO load sits in a branch, and the
+    // residual of group g + 1 (4 channels x 4 time steps) is in flight while group g is scaled and stored.  Before, every one of the
+    // 4 NT groups issued its loads behind per-element `has_res ? load : 0` branches and waited vmcnt(0) before EVERY store: 8 - 16
+    // exposed memory latencies per workgroup at one or two workgroups per CU.
     {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
         const int f = f0 + prow;
         const int t = t0 + tt0;
         const bool pv = f < a.F && t < a.T;
-        const long sp = pv ? (long)f * a.T + t : 0;
         const bool has_os = a.oscale != nullptr, has_res = a.res != nullptr;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (long)b * a.out_bs), 0, (unsigned)(a.Cout * a.out_cs * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc((void*)(has_res ? a.res + (long)b * a.res_bs : a.out), 0,
+                                                                             has_res ? (unsigned)(a.Cout * a.res_cs * 4) : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)(has_os ? a.oscale + (long)b * a.Cout : a.out), 0,
+                                                                             has_os ? (unsigned)(a.Cout * 4) : 0u, 0x00020000);
+        const unsigned sp = pv ? (unsigned)(f * a.T + t) * 4u : 0x80000000u;
+        const unsigned ocs = (unsigned)a.out_cs * 4u, rcs = (unsigned)a.res_cs * 4u;
+        const float os_m = has_os ? a.alpha : 0.f, os_a = has_os ? 0.f : a.alpha;      // scale = fma(oscale, os_m, os_a)
+        constexpr int NG = NT * 4;
+        auto chan = [&](int gi) { return co0 + wr * (NT * 32) + (gi >> 2) * 32 + 8 * (gi & 3) + 4 * h; };
+        f32x4 rv[2][4];
+        float sv[2][4];
+        auto load_group = [&](int gi, f32x4 (&dr)[4], float (&ds)[4]) __attribute__((always_inline)) {
+            const unsigned cq = (unsigned)chan(gi);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+            for (int k = 0; k < 4; ++k) {
+                ds[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, (cq + k) * 4u, 0, 0));
+                dr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_, sp + (cq + k) * rcs, 0, 0));
+            }
+        };
+        load_group(0, rv[0], sv[0]);
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int co_q = co0 + wr * (NT * 32) + nt * 32 + 8 * qd + 4 * h;
-                int cc[4];
-                float os[4];
-                f32x4 rr[4];
+        for (int gi = 0; gi < NG; ++gi) {
+            if (gi + 1 < NG) load_group(gi + 1, rv[(gi + 1) & 1], sv[(gi + 1) & 1]);
+            const int nt = gi >> 2, qd = gi & 3;
+            const unsigned cq = (unsigned)chan(gi);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    cc[k] = co_q + k < a.Cout ? co_q + k : a.Cout - 1;
-                    os[k] = has_os ? a.oscale[b * a.Cout + cc[k]] : 1.f;
-                    rr[k] = has_res ? *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + (long)cc[k] * a.res_cs + sp)
-                                    : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int r = 4 * qd + k;
-                    f32x4 y = {acc[nt][0][r], acc[nt][1][r], acc[nt][2][r], acc[nt][3][r]};
-                    y = y * (a.alpha * os[k]) + a.rbeta * rr[k];
-                    if (pv && co_q + k < a.Cout)
-                        *reinterpret_cast<f32x4*>(a.out + (long)b * a.out_bs + (long)(co_q + k) * a.out_cs + sp) = y;
-                }
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * qd + k;
+                const float sc = __builtin_fmaf(sv[gi & 1][k], os_m, os_a);
+                const f32x4 rk = rv[gi & 1][k];
+                f32x4 y;
+                y[0] = __builtin_fmaf(acc[nt][0][r], sc, a.rbeta * rk[0]);
+                y[1] = __builtin_fmaf(acc[nt][1][r], sc, a.rbeta * rk[1]);
+                y[2] = __builtin_fmaf(acc[nt][2][r], sc, a.rbeta * rk[2]);
+                y[3] = __builtin_fmaf(acc[nt][3][r], sc, a.rbeta * rk[3]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, y), ro, sp + (cq + k) * ocs, 0, 0);
             }
         }
     }
@@ -431,6 +450,8 @@ int babe_conv2d_bf16p_supported(const babe_conv_args& a) {
     if (!al16(a.out) || (a.out_bs & 3) || (a.out_cs & 3)) return 0;                   // 16-byte epilogue vectors
     if (a.res && (!al16(a.res) || (a.res_bs & 3) || (a.res_cs & 3))) return 0;
     const long lim = 0x7fffffffL / 4;
+    // (the epilogue addresses out / res of a batch item through buffer descriptors with 32-bit byte offsets)
+    if ((long)((a.Cout + 31) / 32 * 32) * a.out_cs >= lim || (a.res && (long)((a.Cout + 31) / 32 * 32) * a.res_cs >= lim)) return 0;
     const int split = a.in2 ? a.cin_split : a.Cin;
     if ((long)split * a.in_cs >= lim) return 0;
     if (a.in2 && (long)(a.Cin - split) * a.in2_cs >= lim) return 0;
