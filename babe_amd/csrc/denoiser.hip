@@ -176,28 +176,49 @@ __global__ __launch_bounds__(256, 2) void dn_conv_kernel(babe_dnconv_args a, con
             }
         return;
     }
-    // ---- epilogue: bias, ELU, residual; output index = logical index * out_step + out_off (both axes)
+    // ---- epilogue: bias, ELU, residual; output index = logical index * out_step + out_off (both axes).
+    // Round 6: the bias and residual loads of a 32 x 32 tile are issued back to back inside ONE wave-uniform branch per operand, from
+    // clamped addresses (an element outside the output reads a valid one and is masked at the store).  Under the per-element
+    // `if (ok) { v += a.bias ? a.bias[co] : 0; if (a.res) v += a.res[..]; }` this replaces, every one of a lane's 64 outputs loaded and
+    // waited vmcnt(0) on its own: 64 - 128 exposed memory latencies per workgroup (the same finding as conv_wino85.hip's epilogue).
     const int fh = oh * a.out_hstep + a.out_h0;
     const bool rowok = oh < a.OH && fh >= 0 && fh < a.out_H;
+    const bool has_b = a.bias != nullptr, has_r = a.res != nullptr;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 2; ++nt) {
+        int cc[16];
+        float bs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            cc[r] = co < a.Cout ? co : a.Cout - 1;
+            bs[r] = 0.f;
+        }
+        if (has_b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bs[r] = a.bias[cc[r]];
+        }
 #pragma unroll
         for (int bt = 0; bt < 2; ++bt) {
             const int ow = ow0 + bt * 32 + l31;
             const int fw = ow * a.out_wstep + a.out_w0;
             const bool ok = rowok && ow < a.OW && fw >= 0 && fw < a.out_W;
+            const long sp = ok ? (long)fh * a.out_W + fw : 0;
+            float rv[16];
+            if (has_r) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = a.res[(long)b * a.res_bs + (long)cc[r] * a.res_cs + sp];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (ok && co < a.Cout) {
-                    float v = acc[nt][bt][r] + (a.bias ? a.bias[co] : 0.f);
-                    if (a.act) v = v > 0.f ? v : expm1f(v);
-                    const long sp = (long)fh * a.out_W + fw;
-                    if (a.res) v += a.res[(long)b * a.res_bs + (long)co * a.res_cs + sp];
-                    a.out[(long)b * a.out_bs + (long)co * a.out_cs + sp] = v;
-                }
+                float v = acc[nt][bt][r] + bs[r];
+                if (a.act) v = v > 0.f ? v : expm1f(v);
+                if (has_r) v += rv[r];
+                if (ok && co < a.Cout) a.out[(long)b * a.out_bs + (long)co * a.out_cs + sp] = v;
             }
         }
+    }
 }
 
 // sum of the split-K partials + the conv epilogue
